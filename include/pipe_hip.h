@@ -1,0 +1,178 @@
+/*
+ * pipe_hip.h -- C ABI of the MI355X (gfx950) Processor stage bodies for
+ * pipelined.dev/pipe.
+ *
+ * The reference has no FFI: its plugin seam is the Go function-type API
+ *     ProcessorAllocatorFunc(mctx, bufferSize, input SignalProperties) (Processor, error)
+ *                                                                   line.go:26-30
+ *     Processor{mutable.Context, ProcessFunc, StartFunc, FlushFunc, SignalProperties}
+ *                                                                   pipe.go:49-60
+ * A GPU Processor is an allocator closure whose hooks call the entry points
+ * below through cgo (the shim is in INTEGRATION.md).  Each entry point names the
+ * reference interface it stands behind.  All functions return a pipe_hip_status
+ * (0 = ok); none of them throws, none of them takes or returns a C++/torch type.
+ *
+ * Threading: goroutines migrate between OS threads and HIP's current device is
+ * per thread, so EVERY entry point selects the handle's device itself.  A handle
+ * is never entered concurrently by the pipe (run.go:38-52, merger.go:25-30), and
+ * different handles share no mutable state.
+ *
+ * Buffers are interleaved frames x channels (the layout of signal.Floating as
+ * the north star defines it); "frames" is what the reference calls Samples /
+ * Length (mock.go:43-46,95).
+ */
+#ifndef PIPE_HIP_H
+#define PIPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIPE_HIP_ABI_VERSION 1
+
+typedef enum pipe_hip_status {
+    PIPE_HIP_OK = 0,
+    PIPE_HIP_EINVAL = 1,   /* bad argument (allocator error: surfaces from pipe.New, line.go:72-74) */
+    PIPE_HIP_ENODEV = 2,   /* no such HIP device / no GPU visible */
+    PIPE_HIP_EHIP = 3,     /* a HIP runtime call failed; pipe_hip_last_hip_error() has the code */
+    PIPE_HIP_ENOMEM = 4,
+    PIPE_HIP_ECAP = 5,     /* output would exceed out_cap_frames (pipe.go:437-443: out is bufferSize) */
+    PIPE_HIP_ESTATE = 6    /* call out of order (e.g. collect without submit) */
+} pipe_hip_status;
+
+typedef enum pipe_hip_dtype {
+    PIPE_HIP_F32 = 0, /* float32 buffers (north-star metric) */
+    PIPE_HIP_F64 = 1  /* float64 buffers (what the reference allocates: pipe.go:394,437) */
+} pipe_hip_dtype;
+
+/* parameters that a mutation may change between two buffers
+ * (mutable.Mutation applied at pipe.go:433, before ProcessFunc) */
+typedef enum pipe_hip_param {
+    PIPE_HIP_PARAM_GAIN = 0,   /* 1 value                          */
+    PIPE_HIP_PARAM_TAPS = 1,   /* ntaps values (count must match)  */
+    PIPE_HIP_PARAM_COEFFS = 2  /* nsections*5 values {b0,b1,b2,a1,a2} */
+} pipe_hip_param;
+
+/* Opaque Processor handle: the state a Go closure would capture. */
+typedef struct pipe_hip_processor pipe_hip_processor;
+
+/* What the allocator receives: bufferSize (line.go:27) and the input
+ * SignalProperties (line.go:38-41), plus placement. */
+typedef struct pipe_hip_config {
+    int32_t device;      /* HIP device ordinal */
+    int32_t buffer_size; /* frames per pipe buffer (pipe.go:90,107) */
+    int32_t channels;    /* input SignalProperties.Channels */
+    int32_t dtype;       /* pipe_hip_dtype of in and out buffers */
+    int32_t lines;       /* independent Lines driven by this handle (>= 1); state is per Line,
+                            parameters are shared -- "N parallel Lines, same chain"            */
+    int32_t max_batch;   /* max consecutive buffers per Line in one pipe_hip_process_batch (>= 1) */
+} pipe_hip_config;
+
+/* ---- allocators: the body of a ProcessorAllocatorFunc (line.go:26-30) ------ */
+/* y = x * gain */
+int pipe_hip_gain_create(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out);
+/* direct-form FIR, same taps for every channel; 1 <= ntaps <= 4096 */
+int pipe_hip_fir_create(const pipe_hip_config *cfg, const double *taps, int32_t ntaps,
+                        pipe_hip_processor **out);
+/* DF2T biquad cascade; coeffs = nsections x {b0,b1,b2,a1,a2}; 1 <= nsections <= 8 */
+int pipe_hip_biquad_create(const pipe_hip_config *cfg, const double *coeffs, int32_t nsections,
+                           pipe_hip_processor **out);
+/* rational polyphase resampler: proto has up*taps_per_phase taps, phase p uses
+ * proto[p + j*up].  Output SampleRate = input * up / down.  An up-sampler cannot
+ * live behind ProcessFunc with full buffers: out_cap_frames is
+ * checked and PIPE_HIP_ECAP returned, nothing consumed. */
+int pipe_hip_resampler_create(const pipe_hip_config *cfg, const double *proto,
+                              int32_t taps_per_phase, int32_t up, int32_t down,
+                              pipe_hip_processor **out);
+/* n-input sum ((in0+in1)+in2)...; 2 <= inputs <= 8.  (The reference's merger.go
+ * merges error channels, not signals: SURVEY.md F2.) */
+int pipe_hip_mix_create(const pipe_hip_config *cfg, int32_t inputs, pipe_hip_processor **out);
+/* A Line's Processors slice (line.go:17) run back to back on the device with
+ * float64 intermediates that never leave HBM/LDS.  Takes ownership of the stages
+ * (destroying the chain destroys them).  All stages must share cfg. */
+int pipe_hip_chain_create(pipe_hip_processor *const *stages, int32_t n_stages,
+                          pipe_hip_processor **out);
+
+/* Output SignalProperties the allocator must return (line.go:75, pipe.go:418):
+ * channels, and the SampleRate ratio as up/down. */
+int pipe_hip_output_properties(const pipe_hip_processor *p, int32_t *channels,
+                               int32_t *rate_up, int32_t *rate_down);
+
+/* ---- hooks -------------------------------------------------------------------- */
+/* StartFunc (pipe.go:82-83; called at run.go:64-74,177,201): zero all per-Line
+ * state.  A pipe may be started again (pipe_test.go:108-131). */
+int pipe_hip_start(pipe_hip_processor *p);
+/* FlushFunc (pipe.go:84-86; run.go:54-62): drain the handle's stream. */
+int pipe_hip_flush(pipe_hip_processor *p);
+/* Releases device and pinned memory.  (Go has no destructor hook; the shim ties
+ * it to FlushFunc of the last run or a finalizer.) */
+int pipe_hip_destroy(pipe_hip_processor *p);
+
+/* ProcessFunc(in, out signal.Floating) (int, error)   pipe.go:62-64, called at :438.
+ * in/out are HOST pointers, lines x frames x channels interleaved, element type
+ * cfg.dtype.  in_frames <= buffer_size (short last buffer, pipe.go:404-406).  The
+ * call is synchronous: on return `out` holds *out_frames frames per Line (the
+ * return value the pipe uses to Slice, pipe.go:441-443) and `in` may be freed by
+ * the pipe (pipe.go:431).  in and out must not alias. */
+int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, void *out,
+                     int32_t out_cap_frames, int32_t *out_frames);
+/* ProcessFunc for the n-input mix: ins[i] are HOST pointers of `frames` frames. */
+int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
+                         int32_t frames, void *out);
+
+/* Depth-1 asynchronous form of ProcessFunc, mirroring fitting.Async's channel of
+ * capacity 1 (internal/fitting/fitting.go:56-60): submit() stages buffer k and
+ * returns while the device works; collect() blocks for buffer k.  At most one
+ * buffer may be in flight per handle (PIPE_HIP_ESTATE otherwise). */
+int pipe_hip_submit(pipe_hip_processor *p, const void *in, int32_t in_frames);
+int pipe_hip_collect(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames);
+
+/* A mutable.Mutation body (mutable/mutable.go:40-48) for this component: takes
+ * effect for the next buffer and never for one already submitted (pipe.go:433). */
+int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *values, int32_t count);
+
+/* ---- device-resident batch (multiLineExecutor step, run.go:112-132, widened on
+ * the time axis): every Line advances by frames_per_line frames in one launch.
+ * d_in/d_out are DEVICE pointers on cfg.device, element (line, frame, ch) at
+ * ((line*frames_per_line + frame)*channels + ch); frames_per_line <=
+ * buffer_size*max_batch.  Asynchronous on `stream` (a hipStream_t, NULL = the
+ * handle's own stream); state carries to the next call exactly as if the frames
+ * had been processed buffer by buffer.  For the resampler *out_frames (may be
+ * NULL otherwise) receives the frames written per Line and d_out must hold
+ * out_cap_frames per Line. */
+int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,
+                           int64_t frames_per_line, void *stream);
+int pipe_hip_resample_batch(pipe_hip_processor *p, const void *d_in, int64_t in_frames_per_line,
+                            void *d_out, int64_t out_cap_frames, int64_t *out_frames, void *stream);
+int pipe_hip_mix_batch(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs,
+                       void *d_out, int64_t frames_per_line, void *stream);
+
+/* ---- measurement -------------------------------------------------------------- */
+/* When enabled, every batch launch of the handle's dominant kernel is bracketed
+ * by hipEvents on the launch stream; kernel_time() synchronises and returns the
+ * accumulated milliseconds and launch count since the last reset. */
+int pipe_hip_set_profiling(pipe_hip_processor *p, int32_t enabled);
+int pipe_hip_kernel_time(pipe_hip_processor *p, double *total_ms, int64_t *launches, int32_t reset);
+/* name of the dominant kernel variant the last batch call launched */
+const char *pipe_hip_kernel_name(const pipe_hip_processor *p);
+
+/* ---- utilities ------------------------------------------------------------------ */
+int pipe_hip_abi_version(void);
+const char *pipe_hip_strerror(int status);
+int pipe_hip_last_hip_error(void);
+int pipe_hip_device_count(int32_t *count);
+/* pinned host memory for the shim's staging buffers (the PoolAllocator analogue
+ * of pipe.go:490-492 on the host side of the DMA) */
+int pipe_hip_host_alloc(int64_t bytes, void **ptr);
+int pipe_hip_host_free(void *ptr);
+/* SplitMix64 synthetic stream written on the device:
+ * sample i = ((splitmix64(seed, first_index+i) >> 40) * 2^-23) - 1 */
+int pipe_hip_synth_fill(int32_t device, void *d_out, int32_t dtype, uint64_t seed,
+                        int64_t first_index, int64_t samples, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPE_HIP_H */

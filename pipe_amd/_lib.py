@@ -1,0 +1,88 @@
+"""ctypes binding of libpipe_hip.so (include/pipe_hip.h).
+
+There is no CPU fallback: if the HIP library has not been built, or cannot be
+loaded, importing a Processor fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpipe_hip.so")
+
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE = range(7)
+F32, F64 = 0, 1
+PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("buffer_size", C.c_int32), ("channels", C.c_int32),
+                ("dtype", C.c_int32), ("lines", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class PipeHipError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        msg = lib().pipe_hip_strerror(status).decode()
+        hip = lib().pipe_hip_last_hip_error() if status == EHIP else 0
+        super().__init__(f"{what}: {msg} (status {status}" + (f", hipError {hip})" if hip else ")"))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). pipe_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    dp = C.POINTER(C.c_double)
+    hp = C.POINTER(vp)
+    cfgp = C.POINTER(Config)
+    protos = {
+        "pipe_hip_abi_version": (C.c_int, []),
+        "pipe_hip_strerror": (C.c_char_p, [C.c_int]),
+        "pipe_hip_last_hip_error": (C.c_int, []),
+        "pipe_hip_device_count": (C.c_int, [C.POINTER(i32)]),
+        "pipe_hip_gain_create": (C.c_int, [cfgp, dbl, hp]),
+        "pipe_hip_fir_create": (C.c_int, [cfgp, dp, i32, hp]),
+        "pipe_hip_biquad_create": (C.c_int, [cfgp, dp, i32, hp]),
+        "pipe_hip_resampler_create": (C.c_int, [cfgp, dp, i32, i32, i32, hp]),
+        "pipe_hip_mix_create": (C.c_int, [cfgp, i32, hp]),
+        "pipe_hip_chain_create": (C.c_int, [hp, i32, hp]),
+        "pipe_hip_output_properties": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "pipe_hip_start": (C.c_int, [vp]),
+        "pipe_hip_flush": (C.c_int, [vp]),
+        "pipe_hip_destroy": (C.c_int, [vp]),
+        "pipe_hip_process": (C.c_int, [vp, vp, i32, vp, i32, C.POINTER(i32)]),
+        "pipe_hip_mix_process": (C.c_int, [vp, hp, i32, i32, vp]),
+        "pipe_hip_submit": (C.c_int, [vp, vp, i32]),
+        "pipe_hip_collect": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
+        "pipe_hip_set_param": (C.c_int, [vp, i32, dp, i32]),
+        "pipe_hip_process_batch": (C.c_int, [vp, vp, vp, i64, vp]),
+        "pipe_hip_resample_batch": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(i64), vp]),
+        "pipe_hip_mix_batch": (C.c_int, [vp, hp, i32, vp, i64, vp]),
+        "pipe_hip_set_profiling": (C.c_int, [vp, i32]),
+        "pipe_hip_kernel_time": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i64), i32]),
+        "pipe_hip_kernel_name": (C.c_char_p, [vp]),
+        "pipe_hip_host_alloc": (C.c_int, [i64, hp]),
+        "pipe_hip_host_free": (C.c_int, [vp]),
+        "pipe_hip_synth_fill": (C.c_int, [i32, vp, i32, C.c_uint64, i64, i64, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(L, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != OK:
+        raise PipeHipError(status, what)

@@ -1,0 +1,509 @@
+// The extern "C" surface declared in include/pipe_hip.h, plus the parts of the
+// handle that every Processor kind shares: device selection, the handle's stream,
+// pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
+// bracket used for live kernel timing.
+#include "common.hpp"
+
+namespace pipehip {
+
+thread_local int g_last_hip_error = 0;
+
+// ---- KernelTimer -------------------------------------------------------------
+KernelTimer::~KernelTimer()
+{
+    for (auto &p : ring_) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+}
+
+int KernelTimer::drain()
+{
+    for (size_t i = 0; i < used_; ++i) {
+        PH_HIP(hipEventSynchronize(ring_[i].b));
+        float ms = 0.f;
+        PH_HIP(hipEventElapsedTime(&ms, ring_[i].a, ring_[i].b));
+        total_ms_ += (double)ms;
+        launches_ += 1;
+    }
+    used_ = 0;
+    return PIPE_HIP_OK;
+}
+
+int KernelTimer::begin(hipStream_t s)
+{
+    if (!enabled_)
+        return PIPE_HIP_OK;
+    if (used_ == ring_.size()) {
+        if (ring_.size() >= 1024) {
+            PH_TRY(drain());
+        } else {
+            Pair p{};
+            PH_HIP(hipEventCreate(&p.a));
+            PH_HIP(hipEventCreate(&p.b));
+            ring_.push_back(p);
+        }
+    }
+    PH_HIP(hipEventRecord(ring_[used_].a, s));
+    open_ = true;
+    return PIPE_HIP_OK;
+}
+
+int KernelTimer::end(hipStream_t s)
+{
+    if (!enabled_ || !open_)
+        return PIPE_HIP_OK;
+    PH_HIP(hipEventRecord(ring_[used_].b, s));
+    used_ += 1;
+    open_ = false;
+    return PIPE_HIP_OK;
+}
+
+int KernelTimer::collect(double *total_ms, int64_t *launches, bool reset)
+{
+    PH_TRY(drain());
+    if (total_ms)
+        *total_ms = total_ms_;
+    if (launches)
+        *launches = launches_;
+    if (reset) {
+        total_ms_ = 0.0;
+        launches_ = 0;
+    }
+    return PIPE_HIP_OK;
+}
+
+int validate_config(const pipe_hip_config *c)
+{
+    if (!c)
+        return PIPE_HIP_EINVAL;
+    if (c->buffer_size < 1 || c->channels < 1 || c->channels > 64 || c->lines < 1 ||
+        c->max_batch < 1)
+        return PIPE_HIP_EINVAL;
+    if (c->dtype != PIPE_HIP_F32 && c->dtype != PIPE_HIP_F64)
+        return PIPE_HIP_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return PIPE_HIP_ENODEV;
+    }
+    if (c->device < 0 || c->device >= n)
+        return PIPE_HIP_ENODEV;
+    return PIPE_HIP_OK;
+}
+
+}  // namespace pipehip
+
+using namespace pipehip;
+
+// ---- shared handle plumbing ---------------------------------------------------
+pipe_hip_processor::~pipe_hip_processor()
+{
+    if (cfg.buffer_size > 0)
+        (void)hipSetDevice(cfg.device);
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+    }
+    if (done)
+        (void)hipEventDestroy(done);
+}
+
+int pipe_hip_processor::select_device() const
+{
+    PH_HIP(hipSetDevice(cfg.device));
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_processor::init_common(const pipe_hip_config *c)
+{
+    PH_TRY(validate_config(c));
+    cfg = *c;
+    PH_TRY(select_device());
+    PH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PH_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return PIPE_HIP_OK;
+}
+
+// Staging for the host-pointer form: one pipe buffer per Line in, the largest
+// possible output per Line out.  Allocated on first use so that handles driven
+// only through the device-resident batch entry never pay for it.
+int pipe_hip_processor::ensure_staging()
+{
+    if (d_in.p)
+        return PIPE_HIP_OK;
+    const size_t es = dtype_size(cfg.dtype);
+    const size_t in_b = es * (size_t)cfg.lines * (size_t)cfg.buffer_size * (size_t)cfg.channels;
+    const size_t out_f = (size_t)max_out_frames(cfg.buffer_size);
+    const size_t out_b = es * (size_t)cfg.lines * out_f * (size_t)out_channels();
+    PH_TRY(d_in.alloc(in_b));
+    PH_TRY(d_out.alloc(out_b));
+    PH_TRY(h_in.alloc(in_b));
+    PH_TRY(h_out.alloc(out_b));
+    return PIPE_HIP_OK;
+}
+
+namespace {
+
+int finish_create(int rc, pipe_hip_processor **out)
+{
+    if (rc != PIPE_HIP_OK && out)
+        *out = nullptr;
+    return rc;
+}
+
+// stage `in` and queue H2D -> stage body -> D2H on the handle's stream
+int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_t out_cap_hint)
+{
+    if (!p->single_input())
+        return PIPE_HIP_EINVAL;
+    if (in_frames < 0 || in_frames > p->cfg.buffer_size || (!in && in_frames > 0))
+        return PIPE_HIP_EINVAL;
+    if (p->in_flight)
+        return PIPE_HIP_ESTATE;
+    PH_TRY(p->select_device());
+    PH_TRY(p->ensure_staging());
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t in_b = es * (size_t)p->cfg.lines * (size_t)in_frames * (size_t)p->cfg.channels;
+    int64_t out_frames = in_frames;
+    // the output Line stride of a rate changer is its capacity; fixed-rate
+    // stages pack Lines at in_frames like the input
+    const int64_t cap = p->fixed_rate() ? (int64_t)in_frames : p->max_out_frames(p->cfg.buffer_size);
+    if (!p->fixed_rate()) {
+        const int64_t need = p->out_frames_for(in_frames);
+        if (out_cap_hint >= 0 && need > out_cap_hint)
+            return PIPE_HIP_ECAP;
+    } else if (out_cap_hint >= 0 && in_frames > out_cap_hint) {
+        return PIPE_HIP_ECAP;
+    }
+    if (in_b) {
+        std::memcpy(p->h_in.p, in, in_b);
+        PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
+    }
+    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, in_frames, p->d_out.p, p->cfg.dtype, cap, &out_frames,
+                      p->stream));
+    const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
+                         (size_t)p->out_channels();
+    if (out_b)
+        PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
+    PH_HIP(hipEventRecord(p->done, p->stream));
+    p->in_flight = true;
+    p->in_flight_out_frames = (int32_t)out_frames;
+    return PIPE_HIP_OK;
+}
+
+int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames)
+{
+    if (!p->in_flight)
+        return PIPE_HIP_ESTATE;
+    PH_TRY(p->select_device());
+    PH_HIP(hipEventSynchronize(p->done));
+    p->in_flight = false;
+    const int32_t n = p->in_flight_out_frames;
+    if (n > out_cap_frames)
+        return PIPE_HIP_ECAP;
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t row = es * (size_t)n * (size_t)p->out_channels();
+    if (row && !out)
+        return PIPE_HIP_EINVAL;
+    if (p->fixed_rate() || p->cfg.lines == 1) {
+        if (row)
+            std::memcpy(out, p->h_out.p, row * (size_t)p->cfg.lines);
+    } else {
+        // rate changer with several Lines: device rows are `cap` frames apart,
+        // the caller's are out_cap_frames apart
+        const size_t src_stride = es * (size_t)p->max_out_frames(p->cfg.buffer_size) * (size_t)p->out_channels();
+        const size_t dst_stride = es * (size_t)out_cap_frames * (size_t)p->out_channels();
+        for (int l = 0; l < p->cfg.lines; ++l)
+            std::memcpy((char *)out + dst_stride * l, (const char *)p->h_out.p + src_stride * l, row);
+    }
+    if (out_frames)
+        *out_frames = n;
+    return PIPE_HIP_OK;
+}
+
+}  // namespace
+
+// ---- extern "C" ----------------------------------------------------------------
+extern "C" {
+
+int pipe_hip_abi_version(void) { return PIPE_HIP_ABI_VERSION; }
+
+const char *pipe_hip_strerror(int status)
+{
+    switch (status) {
+    case PIPE_HIP_OK: return "ok";
+    case PIPE_HIP_EINVAL: return "invalid argument";
+    case PIPE_HIP_ENODEV: return "no such HIP device";
+    case PIPE_HIP_EHIP: return "HIP runtime error";
+    case PIPE_HIP_ENOMEM: return "out of memory";
+    case PIPE_HIP_ECAP: return "output exceeds buffer capacity";
+    case PIPE_HIP_ESTATE: return "call out of order";
+    default: return "unknown status";
+    }
+}
+
+int pipe_hip_last_hip_error(void) { return g_last_hip_error; }
+
+int pipe_hip_device_count(int32_t *count)
+{
+    if (!count)
+        return PIPE_HIP_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return PIPE_HIP_ENODEV;
+    }
+    *count = n;
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_gain_create(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_gain(cfg, gain, out), out);
+}
+
+int pipe_hip_fir_create(const pipe_hip_config *cfg, const double *taps, int32_t ntaps,
+                        pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_fir(cfg, taps, ntaps, out), out);
+}
+
+int pipe_hip_biquad_create(const pipe_hip_config *cfg, const double *coeffs, int32_t nsections,
+                           pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_biquad(cfg, coeffs, nsections, out), out);
+}
+
+int pipe_hip_resampler_create(const pipe_hip_config *cfg, const double *proto, int32_t taps_per_phase,
+                              int32_t up, int32_t down, pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_resampler(cfg, proto, taps_per_phase, up, down, out), out);
+}
+
+int pipe_hip_mix_create(const pipe_hip_config *cfg, int32_t inputs, pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_mix(cfg, inputs, out), out);
+}
+
+int pipe_hip_chain_create(pipe_hip_processor *const *stages, int32_t n_stages, pipe_hip_processor **out)
+{
+    if (!out)
+        return PIPE_HIP_EINVAL;
+    return finish_create(make_chain(stages, n_stages, out), out);
+}
+
+int pipe_hip_output_properties(const pipe_hip_processor *p, int32_t *channels, int32_t *rate_up,
+                               int32_t *rate_down)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    int32_t up = 1, down = 1;
+    p->rate(&up, &down);
+    if (channels)
+        *channels = p->out_channels();
+    if (rate_up)
+        *rate_up = up;
+    if (rate_down)
+        *rate_down = down;
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_start(pipe_hip_processor *p)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    if (p->in_flight) {  // a restarted pipe drops whatever was in flight
+        PH_HIP(hipEventSynchronize(p->done));
+        p->in_flight = false;
+    }
+    PH_TRY(p->start(p->stream));
+    PH_HIP(hipStreamSynchronize(p->stream));
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_flush(pipe_hip_processor *p)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    PH_HIP(hipStreamSynchronize(p->stream));
+    p->in_flight = false;
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_destroy(pipe_hip_processor *p)
+{
+    if (!p)
+        return PIPE_HIP_OK;
+    if (p->owned_by_chain)
+        return PIPE_HIP_EINVAL;
+    (void)hipSetDevice(p->cfg.device);
+    (void)hipDeviceSynchronize();
+    delete p;
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_submit(pipe_hip_processor *p, const void *in, int32_t in_frames)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    return submit_impl(p, in, in_frames, -1);
+}
+
+int pipe_hip_collect(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    return collect_impl(p, out, out_cap_frames, out_frames);
+}
+
+int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, void *out,
+                     int32_t out_cap_frames, int32_t *out_frames)
+{
+    if (!p || out_cap_frames < 0)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
+    return collect_impl(p, out, out_cap_frames, out_frames);
+}
+
+int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
+                         int32_t frames, void *out)
+{
+    if (!p || !ins || frames < 0 || frames > p->cfg.buffer_size || n_inputs < 2 || n_inputs > 8)
+        return PIPE_HIP_EINVAL;
+    if (p->single_input())
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t one = es * (size_t)p->cfg.lines * (size_t)frames * (size_t)p->cfg.channels;
+    const size_t cap = es * (size_t)p->cfg.lines * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels;
+    // staging: n input slots + 1 output slot, allocated once
+    if (!p->d_in.p) {
+        PH_TRY(p->d_in.alloc(cap * 8));
+        PH_TRY(p->d_out.alloc(cap));
+        PH_TRY(p->h_in.alloc(cap * 8));
+        PH_TRY(p->h_out.alloc(cap));
+    }
+    const void *d_ins[8] = {};
+    for (int i = 0; i < n_inputs; ++i) {
+        if (!ins[i] && one)
+            return PIPE_HIP_EINVAL;
+        char *h = (char *)p->h_in.p + cap * i;
+        char *d = (char *)p->d_in.p + cap * i;
+        if (one) {
+            std::memcpy(h, ins[i], one);
+            PH_HIP(hipMemcpyAsync(d, h, one, hipMemcpyHostToDevice, p->stream));
+        }
+        d_ins[i] = d;
+    }
+    PH_TRY(mix_run(p, d_ins, n_inputs, p->d_out.p, frames, p->stream));
+    if (one)
+        PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, one, hipMemcpyDeviceToHost, p->stream));
+    PH_HIP(hipStreamSynchronize(p->stream));
+    if (one)
+        std::memcpy(out, p->h_out.p, one);
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *values, int32_t count)
+{
+    if (!p || !values || count < 1)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    return p->set_param(param, values, count);
+}
+
+int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,
+                           int64_t frames_per_line, void *stream)
+{
+    if (!p || frames_per_line < 0 || (frames_per_line > 0 && (!d_in || !d_out)))
+        return PIPE_HIP_EINVAL;
+    if (frames_per_line > (int64_t)p->cfg.buffer_size * p->cfg.max_batch)
+        return PIPE_HIP_EINVAL;
+    if (!p->fixed_rate() || !p->single_input())
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    return p->run(d_in, p->cfg.dtype, d_out, p->cfg.dtype, frames_per_line, s);
+}
+
+int pipe_hip_resample_batch(pipe_hip_processor *p, const void *d_in, int64_t in_frames_per_line,
+                            void *d_out, int64_t out_cap_frames, int64_t *out_frames, void *stream)
+{
+    if (!p || in_frames_per_line < 0 || out_cap_frames < 0 || p->fixed_rate())
+        return PIPE_HIP_EINVAL;
+    if (in_frames_per_line > (int64_t)p->cfg.buffer_size * p->cfg.max_batch)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    return p->run_var(d_in, p->cfg.dtype, in_frames_per_line, d_out, p->cfg.dtype, out_cap_frames,
+                      out_frames, s);
+}
+
+int pipe_hip_mix_batch(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, void *d_out,
+                       int64_t frames_per_line, void *stream)
+{
+    if (!p || !d_ins || !d_out || frames_per_line < 0 || p->single_input())
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    return mix_run(p, d_ins, n_inputs, d_out, frames_per_line, s);
+}
+
+int pipe_hip_set_profiling(pipe_hip_processor *p, int32_t enabled)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    p->timer.enable(enabled != 0);
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_kernel_time(pipe_hip_processor *p, double *total_ms, int64_t *launches, int32_t reset)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    return p->timer.collect(total_ms, launches, reset != 0);
+}
+
+const char *pipe_hip_kernel_name(const pipe_hip_processor *p) { return p ? p->last_kernel : ""; }
+
+int pipe_hip_host_alloc(int64_t bytes, void **ptr)
+{
+    if (!ptr || bytes < 0)
+        return PIPE_HIP_EINVAL;
+    *ptr = nullptr;
+    PH_HIP(hipHostMalloc(ptr, bytes > 0 ? (size_t)bytes : 16, hipHostMallocDefault));
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_host_free(void *ptr)
+{
+    if (ptr)
+        PH_HIP(hipHostFree(ptr));
+    return PIPE_HIP_OK;
+}
+
+int pipe_hip_synth_fill(int32_t device, void *d_out, int32_t dtype, uint64_t seed, int64_t first_index,
+                        int64_t samples, void *stream)
+{
+    if (!d_out || samples < 0 || (dtype != PIPE_HIP_F32 && dtype != PIPE_HIP_F64))
+        return PIPE_HIP_EINVAL;
+    PH_HIP(hipSetDevice(device));
+    return launch_synth_fill(d_out, dtype, seed, first_index, samples, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// A Line's Processors slice (line.go:17) as one device-side chain: stage i's
+// output feeds stage i+1 without leaving the GPU, with float64 intermediates (the
+// element type the reference pipe itself carries between stages: pipe.go:437).
+// Only the first stage reads, and only the last stage writes, buffers of the
+// handle's I/O dtype -- so a float32 chain rounds once, at the end, exactly like
+// `(float)` applied to the oracle's float64 chain.
+#include "common.hpp"
+
+namespace pipehip {
+namespace {
+
+class Chain final : public pipe_hip_processor {
+public:
+    std::vector<std::unique_ptr<pipe_hip_processor>> stages;
+
+    int init()
+    {
+        const size_t n = sizeof(double) * (size_t)cfg.lines * (size_t)cfg.buffer_size *
+                         (size_t)cfg.max_batch * (size_t)cfg.channels;
+        if (stages.size() > 1) {
+            PH_TRY(tmp_[0].alloc(n));
+            if (stages.size() > 2)
+                PH_TRY(tmp_[1].alloc(n));
+        }
+        return PIPE_HIP_OK;
+    }
+    int start(hipStream_t s) override
+    {
+        for (auto &st : stages)
+            PH_TRY(st->start(s));
+        return PIPE_HIP_OK;
+    }
+    int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
+            hipStream_t s) override
+    {
+        const void *src = d_in;
+        int src_dtype = in_dtype;
+        const size_t ns = stages.size();
+        PH_TRY(timer.begin(s));
+        for (size_t i = 0; i < ns; ++i) {
+            const bool last = i + 1 == ns;
+            void *dst = last ? d_out : tmp_[i & 1].p;
+            const int dst_dtype = last ? out_dtype : (int)PIPE_HIP_F64;
+            stages[i]->timer.enable(false);
+            PH_TRY(stages[i]->run(src, src_dtype, dst, dst_dtype, frames, s));
+            src = dst;
+            src_dtype = dst_dtype;
+        }
+        PH_TRY(timer.end(s));
+        last_kernel = stages.empty() ? "" : stages[0]->last_kernel;
+        return PIPE_HIP_OK;
+    }
+    // a mutation addressed to the chain goes to the first stage that owns the parameter
+    int set_param(int32_t param, const double *values, int32_t count) override
+    {
+        for (auto &st : stages)
+            if (st->set_param(param, values, count) == PIPE_HIP_OK)
+                return PIPE_HIP_OK;
+        return PIPE_HIP_EINVAL;
+    }
+
+private:
+    DevBuf tmp_[2];
+};
+
+}  // namespace
+
+int make_chain(pipe_hip_processor *const *stages, int32_t n, pipe_hip_processor **out)
+{
+    if (!stages || n < 1 || n > 16)
+        return PIPE_HIP_EINVAL;
+    const pipe_hip_config c0 = stages[0]->cfg;
+    for (int i = 0; i < n; ++i) {
+        const pipe_hip_processor *s = stages[i];
+        if (!s || s->owned_by_chain)
+            return PIPE_HIP_EINVAL;
+        // every stage must keep rate and channel count (no resampler / mix inside)
+        int32_t up = 1, down = 1;
+        s->rate(&up, &down);
+        if (up != down || s->out_channels() != c0.channels || std::memcmp(&s->cfg, &c0, sizeof c0) != 0)
+            return PIPE_HIP_EINVAL;
+        if (!s->single_input())
+            return PIPE_HIP_EINVAL;
+    }
+    auto p = std::make_unique<Chain>();
+    PH_TRY(p->init_common(&c0));
+    for (int i = 0; i < n; ++i) {
+        stages[i]->owned_by_chain = true;
+        p->stages.emplace_back(stages[i]);
+    }
+    const int rc = p->init();
+    if (rc != PIPE_HIP_OK) {
+        for (auto &st : p->stages) {  // hand the stages back on failure
+            st->owned_by_chain = false;
+            (void)st.release();
+        }
+        return rc;
+    }
+    *out = p.release();
+    return PIPE_HIP_OK;
+}
+
+}  // namespace pipehip

@@ -1,0 +1,198 @@
+// Shared infrastructure of libpipe_hip: the polymorphic Processor handle behind
+// the C ABI in include/pipe_hip.h, error plumbing and small RAII helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "pipe_hip.h"
+
+namespace pipehip {
+
+extern thread_local int g_last_hip_error;
+
+#define PH_HIP(call)                                  \
+    do {                                              \
+        hipError_t e__ = (call);                      \
+        if (e__ != hipSuccess) {                      \
+            ::pipehip::g_last_hip_error = (int)e__;   \
+            (void)hipGetLastError();                  \
+            return PIPE_HIP_EHIP;                     \
+        }                                             \
+    } while (0)
+
+#define PH_TRY(expr)                 \
+    do {                             \
+        int s__ = (expr);            \
+        if (s__ != PIPE_HIP_OK)      \
+            return s__;              \
+    } while (0)
+
+inline size_t dtype_size(int dtype) { return dtype == PIPE_HIP_F64 ? 8 : 4; }
+
+// Device allocation owned by a handle.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0)
+            n = 16;
+        PH_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return PIPE_HIP_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// Pinned host allocation (the host half of a DMA staging pair).
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0)
+            n = 16;
+        PH_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+        return PIPE_HIP_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~PinnedBuf() { release(); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+};
+
+// hipEvent bracket around the dominant kernel of a handle (pipe_hip_set_profiling).
+class KernelTimer {
+public:
+    ~KernelTimer();
+    void enable(bool on) { enabled_ = on; }
+    bool enabled() const { return enabled_; }
+    int begin(hipStream_t s);
+    int end(hipStream_t s);
+    int collect(double *total_ms, int64_t *launches, bool reset);
+
+private:
+    int drain();
+    struct Pair {
+        hipEvent_t a, b;
+    };
+    std::vector<Pair> ring_;
+    size_t used_ = 0;
+    bool enabled_ = false;
+    bool open_ = false;
+    double total_ms_ = 0.0;
+    int64_t launches_ = 0;
+};
+
+}  // namespace pipehip
+
+// The opaque handle of the C ABI.  One object == one Processor component of a
+// Line (pipe.go:49-60) -- or of `lines` identical Lines batched together.
+struct pipe_hip_processor {
+    pipe_hip_config cfg{};
+    hipStream_t stream = nullptr;  // the handle's own stream
+    pipehip::KernelTimer timer;
+    const char *last_kernel = "";
+
+    // host<->device staging for the ProcessFunc form (lazily sized)
+    pipehip::DevBuf d_in, d_out;
+    pipehip::PinnedBuf h_in, h_out;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+    int32_t in_flight_out_frames = 0;
+    bool owned_by_chain = false;
+
+    virtual ~pipe_hip_processor();
+
+    // properties of the OUTPUT signal
+    virtual int out_channels() const { return cfg.channels; }
+    virtual void rate(int32_t *up, int32_t *down) const
+    {
+        *up = 1;
+        *down = 1;
+    }
+    // frames this stage emits per Line for `in_frames` new input frames
+    virtual int64_t out_frames_for(int64_t in_frames) const { return in_frames; }
+    // max output frames per Line for the staging buffers
+    virtual int64_t max_out_frames(int64_t in_frames) const { return in_frames; }
+
+    // false for the n-input mix, which ProcessFunc's single `in` cannot feed
+    virtual bool single_input() const { return true; }
+
+    // zero per-Line state, asynchronously on `s`
+    virtual int start(hipStream_t s) = 0;
+    // advance every Line by `frames` frames.  Device pointers, line-major.
+    virtual int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
+                    hipStream_t s) = 0;
+    // rate-changing form: emits *out_frames (<= out_cap) frames per Line; the
+    // output Line stride is out_cap frames.  Default: out == in frames.
+    virtual int run_var(const void *d_in, int in_dtype, int64_t in_frames, void *d_out, int out_dtype,
+                        int64_t out_cap, int64_t *out_frames, hipStream_t s)
+    {
+        if (in_frames > out_cap)
+            return PIPE_HIP_ECAP;
+        if (out_frames)
+            *out_frames = in_frames;
+        return run(d_in, in_dtype, d_out, out_dtype, in_frames, s);
+    }
+    virtual bool fixed_rate() const { return true; }
+    virtual int set_param(int32_t param, const double *values, int32_t count)
+    {
+        (void)param;
+        (void)values;
+        (void)count;
+        return PIPE_HIP_EINVAL;
+    }
+
+    int init_common(const pipe_hip_config *c);
+    int ensure_staging();
+    int select_device() const;
+};
+
+namespace pipehip {
+
+int validate_config(const pipe_hip_config *cfg);
+
+// factories implemented next to their kernels
+int make_gain(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out);
+int make_fir(const pipe_hip_config *cfg, const double *taps, int32_t ntaps, pipe_hip_processor **out);
+int make_biquad(const pipe_hip_config *cfg, const double *coeffs, int32_t nsections,
+                pipe_hip_processor **out);
+int make_resampler(const pipe_hip_config *cfg, const double *proto, int32_t taps_per_phase,
+                   int32_t up, int32_t down, pipe_hip_processor **out);
+int make_mix(const pipe_hip_config *cfg, int32_t inputs, pipe_hip_processor **out);
+int make_chain(pipe_hip_processor *const *stages, int32_t n, pipe_hip_processor **out);
+
+// n-input mix has its own entry because ProcessFunc has one input
+int mix_run(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, void *d_out,
+            int64_t frames, hipStream_t s);
+
+int launch_synth_fill(void *d_out, int dtype, uint64_t seed, int64_t first, int64_t n, hipStream_t s);
+
+}  // namespace pipehip

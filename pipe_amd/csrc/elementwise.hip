@@ -1,0 +1,246 @@
+// HBM-bound element-wise Processors for gfx950: gain (also the pass-through copy
+// of mock.Processor, mock/mock.go:147-154, at gain == 1), the n-input mix, and the
+// SplitMix64 synthetic source used by the bench.
+//
+// Contract (oracle/dsp_oracle.h): y = (T_out)((double)x * g);  mix = ((a+b)+c)...
+// in binary64.  One 16-byte vector per lane per trip, grid capped at 2048
+// workgroups with a grid-stride loop.
+#include "common.hpp"
+
+namespace pipehip {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+    T v[V];
+};
+
+// elements handled per lane per trip: 4 (16 B of f32, 32 B of f64)
+constexpr int kPer = 4;
+
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(kThreads) gain_kernel(const TIn *__restrict__ in,
+                                                        TOut *__restrict__ out, int64_t n, double g,
+                                                        int vec_ok)
+{
+    const int64_t nvec = vec_ok ? n / kPer : 0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    using PI = Pack<TIn, kPer>;
+    using PO = Pack<TOut, kPer>;
+    const PI *vin = reinterpret_cast<const PI *>(in);
+    PO *vout = reinterpret_cast<PO *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const PI x = vin[i];
+        PO y;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            y.v[k] = (TOut)((double)x.v[k] * g);
+        vout[i] = y;
+    }
+    // tail (or everything, when a pointer is not vector-aligned)
+    for (int64_t t = nvec * kPer + (int64_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride)
+        out[t] = (TOut)((double)in[t] * g);
+}
+
+struct MixPtrs {
+    const void *p[8];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mix_kernel(const MixPtrs ins, int n_inputs,
+                                                       T *__restrict__ out, int64_t n, int vec_ok)
+{
+    const int64_t nvec = vec_ok ? n / kPer : 0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    using P = Pack<T, kPer>;
+    P *vout = reinterpret_cast<P *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        double acc[kPer];
+        const P a = reinterpret_cast<const P *>(ins.p[0])[i];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            acc[k] = (double)a.v[k];
+        for (int j = 1; j < n_inputs; ++j) {
+            const P b = reinterpret_cast<const P *>(ins.p[j])[i];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                acc[k] = acc[k] + (double)b.v[k];
+        }
+        P y;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            y.v[k] = (T)acc[k];
+        vout[i] = y;
+    }
+    for (int64_t t = nvec * kPer + (int64_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
+        double acc = (double)reinterpret_cast<const T *>(ins.p[0])[t];
+        for (int j = 1; j < n_inputs; ++j)
+            acc = acc + (double)reinterpret_cast<const T *>(ins.p[j])[t];
+        out[t] = (T)acc;
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) synth_kernel(T *__restrict__ out, uint64_t seed,
+                                                         int64_t first, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const uint64_t u = splitmix64_at(seed, (uint64_t)(first + i));
+        out[i] = (T)((double)(u >> 40) * 0x1p-23 - 1.0);
+    }
+}
+
+inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline int grid_for(int64_t n_vec)
+{
+    int64_t b = (n_vec + kThreads - 1) / kThreads;
+    if (b < 1)
+        b = 1;
+    if (b > kMaxBlocks)
+        b = kMaxBlocks;
+    return (int)b;
+}
+
+class Gain final : public pipe_hip_processor {
+public:
+    double gain = 1.0;
+    int start(hipStream_t) override { return PIPE_HIP_OK; }
+    int set_param(int32_t param, const double *values, int32_t count) override
+    {
+        if (param != PIPE_HIP_PARAM_GAIN || count != 1 || !values)
+            return PIPE_HIP_EINVAL;
+        gain = values[0];  // a kernel argument: queued launches keep their own copy
+        return PIPE_HIP_OK;
+    }
+    int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
+            hipStream_t s) override
+    {
+        const int64_t n = frames * cfg.channels * cfg.lines;
+        if (n <= 0)
+            return PIPE_HIP_OK;
+        const int vec_ok = aligned_to(d_in, dtype_size(in_dtype) * kPer) &&
+                           aligned_to(d_out, dtype_size(out_dtype) * kPer);
+        const dim3 grid(grid_for(vec_ok ? n / kPer : n));
+        PH_TRY(timer.begin(s));
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+            hipLaunchKernelGGL((gain_kernel<float, float>), grid, dim3(kThreads), 0, s,
+                               (const float *)d_in, (float *)d_out, n, gain, vec_ok);
+            last_kernel = "gain_kernel<f32,f32>";
+        } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
+            hipLaunchKernelGGL((gain_kernel<double, double>), grid, dim3(kThreads), 0, s,
+                               (const double *)d_in, (double *)d_out, n, gain, vec_ok);
+            last_kernel = "gain_kernel<f64,f64>";
+        } else if (in_dtype == PIPE_HIP_F32) {
+            hipLaunchKernelGGL((gain_kernel<float, double>), grid, dim3(kThreads), 0, s,
+                               (const float *)d_in, (double *)d_out, n, gain, vec_ok);
+            last_kernel = "gain_kernel<f32,f64>";
+        } else {
+            hipLaunchKernelGGL((gain_kernel<double, float>), grid, dim3(kThreads), 0, s,
+                               (const double *)d_in, (float *)d_out, n, gain, vec_ok);
+            last_kernel = "gain_kernel<f64,f32>";
+        }
+        PH_HIP(hipGetLastError());
+        PH_TRY(timer.end(s));
+        return PIPE_HIP_OK;
+    }
+};
+
+class Mix final : public pipe_hip_processor {
+public:
+    int inputs = 2;
+    bool single_input() const override { return false; }
+    int start(hipStream_t) override { return PIPE_HIP_OK; }
+    // a mix has no single-input form: ProcessFunc carries one input (pipe.go:62-64)
+    int run(const void *, int, void *, int, int64_t, hipStream_t) override { return PIPE_HIP_EINVAL; }
+    int run_n(const void *const *d_ins, int32_t n_inputs, void *d_out, int64_t frames, hipStream_t s)
+    {
+        if (n_inputs != inputs)
+            return PIPE_HIP_EINVAL;
+        const int64_t n = frames * cfg.channels * cfg.lines;
+        if (n <= 0)
+            return PIPE_HIP_OK;
+        MixPtrs ptrs{};
+        int vec_ok = aligned_to(d_out, dtype_size(cfg.dtype) * kPer);
+        for (int i = 0; i < n_inputs; ++i) {
+            if (!d_ins[i])
+                return PIPE_HIP_EINVAL;
+            ptrs.p[i] = d_ins[i];
+            vec_ok = vec_ok && aligned_to(d_ins[i], dtype_size(cfg.dtype) * kPer);
+        }
+        const dim3 grid(grid_for(vec_ok ? n / kPer : n));
+        PH_TRY(timer.begin(s));
+        if (cfg.dtype == PIPE_HIP_F32) {
+            hipLaunchKernelGGL(mix_kernel<float>, grid, dim3(kThreads), 0, s, ptrs, n_inputs,
+                               (float *)d_out, n, vec_ok);
+            last_kernel = "mix_kernel<f32>";
+        } else {
+            hipLaunchKernelGGL(mix_kernel<double>, grid, dim3(kThreads), 0, s, ptrs, n_inputs,
+                               (double *)d_out, n, vec_ok);
+            last_kernel = "mix_kernel<f64>";
+        }
+        PH_HIP(hipGetLastError());
+        PH_TRY(timer.end(s));
+        return PIPE_HIP_OK;
+    }
+};
+
+}  // namespace
+
+int make_gain(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out)
+{
+    auto p = std::make_unique<Gain>();
+    PH_TRY(p->init_common(cfg));
+    p->gain = gain;
+    *out = p.release();
+    return PIPE_HIP_OK;
+}
+
+int make_mix(const pipe_hip_config *cfg, int32_t inputs, pipe_hip_processor **out)
+{
+    if (inputs < 2 || inputs > 8)
+        return PIPE_HIP_EINVAL;
+    auto p = std::make_unique<Mix>();
+    PH_TRY(p->init_common(cfg));
+    p->inputs = inputs;
+    *out = p.release();
+    return PIPE_HIP_OK;
+}
+
+int mix_run(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, void *d_out,
+            int64_t frames, hipStream_t s)
+{
+    auto *m = dynamic_cast<Mix *>(p);
+    if (!m)
+        return PIPE_HIP_EINVAL;
+    return m->run_n(d_ins, n_inputs, d_out, frames, s);
+}
+
+int launch_synth_fill(void *d_out, int dtype, uint64_t seed, int64_t first, int64_t n, hipStream_t s)
+{
+    if (n <= 0)
+        return PIPE_HIP_OK;
+    const dim3 grid(grid_for(n));
+    if (dtype == PIPE_HIP_F32)
+        hipLaunchKernelGGL(synth_kernel<float>, grid, dim3(kThreads), 0, s, (float *)d_out, seed,
+                           first, n);
+    else
+        hipLaunchKernelGGL(synth_kernel<double>, grid, dim3(kThreads), 0, s, (double *)d_out, seed,
+                           first, n);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
+}  // namespace pipehip

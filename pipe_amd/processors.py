@@ -1,0 +1,281 @@
+"""Python face of the C ABI, used by the tests and bench.py.
+
+Each class is one Processor component as the reference defines it
+(pipe.go:49-60): constructed by an allocator that receives bufferSize and the
+input SignalProperties (line.go:26-30), with the three hooks
+
+    start()   -> StartFunc    (pipe.go:82-83)
+    process() -> ProcessFunc  (pipe.go:62-64)   host buffers, synchronous
+    flush()   -> FlushFunc    (pipe.go:84-86)
+
+plus the device-resident `process_batch` used for roofline runs.  Everything is
+a thin call into libpipe_hip.so; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _np_dtype(dtype) -> np.dtype:
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError("dtype must be float32 or float64")
+    return dt
+
+
+def _code(dt: np.dtype) -> int:
+    return L.F64 if dt == np.dtype(np.float64) else L.F32
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _devptr(t) -> int:
+    """Device pointer of a torch tensor (torch is plumbing only)."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("need a contiguous device tensor")
+    return t.data_ptr()
+
+
+class Processor:
+    """Base: owns a pipe_hip_processor handle."""
+
+    def __init__(self, buffer_size: int, channels: int, dtype=np.float32, device: int = 0,
+                 lines: int = 1, max_batch: int = 1):
+        self.dtype = _np_dtype(dtype)
+        self.buffer_size = int(buffer_size)
+        self.channels = int(channels)
+        self.lines = int(lines)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        self._cfg = L.Config(self.device, self.buffer_size, self.channels, _code(self.dtype),
+                             self.lines, self.max_batch)
+        self._h = C.c_void_p()
+        self._owned = False
+
+    # -- lifecycle ---------------------------------------------------------------
+    def _created(self, status: int, what: str):
+        L.check(status, what)
+        return self
+
+    def start(self):
+        L.check(L.lib().pipe_hip_start(self._h), "start")
+
+    def flush(self):
+        L.check(L.lib().pipe_hip_flush(self._h), "flush")
+
+    def close(self):
+        if self._h and not self._owned:
+            L.lib().pipe_hip_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- properties ------------------------------------------------------------------
+    def output_properties(self):
+        ch, up, down = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(L.lib().pipe_hip_output_properties(self._h, C.byref(ch), C.byref(up), C.byref(down)),
+                "output_properties")
+        return ch.value, up.value, down.value
+
+    # -- ProcessFunc -----------------------------------------------------------------
+    def _shape_in(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        per_line = x.size // self.lines
+        if per_line * self.lines != x.size or per_line % self.channels:
+            raise ValueError("input size does not match lines x frames x channels")
+        return x, per_line // self.channels
+
+    def process(self, x: np.ndarray, out_cap_frames: Optional[int] = None) -> np.ndarray:
+        x, frames = self._shape_in(x)
+        cap = self.buffer_size if out_cap_frames is None else int(out_cap_frames)
+        out_ch, _, _ = self.output_properties()
+        out = np.empty((self.lines, max(cap, 1), out_ch), dtype=self.dtype)
+        n = C.c_int32()
+        L.check(L.lib().pipe_hip_process(self._h, x.ctypes.data, frames, out.ctypes.data, cap,
+                                         C.byref(n)), "process")
+        return self._shape_out(out, cap, n.value)
+
+    def _shape_out(self, out, cap, n):
+        # fixed-rate stages pack Lines at n frames; rate changers at cap frames
+        out_ch = out.shape[2]
+        flat = out.reshape(-1)
+        if self._fixed_rate() or self.lines == 1:
+            res = flat[: self.lines * n * out_ch].reshape(self.lines, n, out_ch)
+        else:
+            res = out[:, :n, :]
+        return res[0].copy() if self.lines == 1 else res.copy()
+
+    def _fixed_rate(self) -> bool:
+        return True
+
+    def submit(self, x: np.ndarray):
+        x, frames = self._shape_in(x)
+        L.check(L.lib().pipe_hip_submit(self._h, x.ctypes.data, frames), "submit")
+
+    def collect(self, out_cap_frames: Optional[int] = None) -> np.ndarray:
+        cap = self.buffer_size if out_cap_frames is None else int(out_cap_frames)
+        out_ch, _, _ = self.output_properties()
+        out = np.empty((self.lines, max(cap, 1), out_ch), dtype=self.dtype)
+        n = C.c_int32()
+        L.check(L.lib().pipe_hip_collect(self._h, out.ctypes.data, cap, C.byref(n)), "collect")
+        return self._shape_out(out, cap, n.value)
+
+    # -- device-resident batch ------------------------------------------------------------
+    def process_batch(self, d_in, d_out, frames_per_line: Optional[int] = None, stream: int = 0):
+        """d_in/d_out: torch device tensors of lines*frames*channels elements."""
+        if frames_per_line is None:
+            frames_per_line = d_in.numel() // (self.lines * self.channels)
+        L.check(L.lib().pipe_hip_process_batch(self._h, _devptr(d_in), _devptr(d_out),
+                                               int(frames_per_line), C.c_void_p(stream or None)),
+                "process_batch")
+
+    # -- measurement -------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        L.check(L.lib().pipe_hip_set_profiling(self._h, 1 if on else 0), "set_profiling")
+
+    def kernel_time(self, reset: bool = True):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().pipe_hip_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0),
+                "kernel_time")
+        return ms.value, n.value
+
+    def kernel_name(self) -> str:
+        return L.lib().pipe_hip_kernel_name(self._h).decode()
+
+    def _set_param(self, param: int, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        L.check(L.lib().pipe_hip_set_param(self._h, param, _dptr(v), v.size), "set_param")
+
+
+class Gain(Processor):
+    def __init__(self, gain: float, buffer_size: int, channels: int, **kw):
+        super().__init__(buffer_size, channels, **kw)
+        self._created(L.lib().pipe_hip_gain_create(C.byref(self._cfg), float(gain), C.byref(self._h)),
+                      "gain_create")
+
+    def set_gain(self, gain: float):
+        self._set_param(L.PARAM_GAIN, [gain])
+
+
+class Copy(Gain):
+    """mock.Processor (mock/mock.go:130-157): the pass-through copy."""
+
+    def __init__(self, buffer_size: int, channels: int, **kw):
+        super().__init__(1.0, buffer_size, channels, **kw)
+
+
+class Fir(Processor):
+    def __init__(self, taps: Sequence[float], buffer_size: int, channels: int, **kw):
+        super().__init__(buffer_size, channels, **kw)
+        t = np.ascontiguousarray(taps, dtype=np.float64).ravel()
+        self.ntaps = t.size
+        self._created(L.lib().pipe_hip_fir_create(C.byref(self._cfg), _dptr(t), t.size,
+                                                  C.byref(self._h)), "fir_create")
+
+    def set_taps(self, taps):
+        self._set_param(L.PARAM_TAPS, taps)
+
+
+class Biquad(Processor):
+    def __init__(self, coeffs, buffer_size: int, channels: int, **kw):
+        super().__init__(buffer_size, channels, **kw)
+        c = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1, 5)
+        self._created(L.lib().pipe_hip_biquad_create(C.byref(self._cfg), _dptr(c), c.shape[0],
+                                                     C.byref(self._h)), "biquad_create")
+
+    def set_coeffs(self, coeffs):
+        self._set_param(L.PARAM_COEFFS, coeffs)
+
+
+class Resampler(Processor):
+    def __init__(self, proto, taps_per_phase: int, up: int, down: int, buffer_size: int,
+                 channels: int, **kw):
+        super().__init__(buffer_size, channels, **kw)
+        p = np.ascontiguousarray(proto, dtype=np.float64).ravel()
+        if p.size != up * taps_per_phase:
+            raise ValueError("proto must have up*taps_per_phase taps")
+        self.up, self.down = up, down
+        self._created(L.lib().pipe_hip_resampler_create(C.byref(self._cfg), _dptr(p), taps_per_phase,
+                                                        up, down, C.byref(self._h)),
+                      "resampler_create")
+
+    def _fixed_rate(self) -> bool:
+        return False
+
+    def resample_batch(self, d_in, in_frames: int, d_out, out_cap_frames: int, stream: int = 0) -> int:
+        n = C.c_int64()
+        L.check(L.lib().pipe_hip_resample_batch(self._h, _devptr(d_in), int(in_frames), _devptr(d_out),
+                                                int(out_cap_frames), C.byref(n),
+                                                C.c_void_p(stream or None)), "resample_batch")
+        return n.value
+
+
+class Mix(Processor):
+    def __init__(self, inputs: int, buffer_size: int, channels: int, **kw):
+        super().__init__(buffer_size, channels, **kw)
+        self.inputs = inputs
+        self._created(L.lib().pipe_hip_mix_create(C.byref(self._cfg), inputs, C.byref(self._h)),
+                      "mix_create")
+
+    def process(self, xs: Sequence[np.ndarray], out_cap_frames=None) -> np.ndarray:  # type: ignore[override]
+        arrs = [np.ascontiguousarray(x, dtype=self.dtype) for x in xs]
+        frames = arrs[0].size // (self.lines * self.channels)
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        out = np.empty_like(arrs[0])
+        L.check(L.lib().pipe_hip_mix_process(self._h, ptrs, len(arrs), frames, out.ctypes.data),
+                "mix_process")
+        return out
+
+    def mix_batch(self, d_ins, d_out, frames_per_line: int, stream: int = 0):
+        ptrs = (C.c_void_p * len(d_ins))(*[_devptr(t) for t in d_ins])
+        L.check(L.lib().pipe_hip_mix_batch(self._h, ptrs, len(d_ins), _devptr(d_out),
+                                           int(frames_per_line), C.c_void_p(stream or None)),
+                "mix_batch")
+
+
+class Chain(Processor):
+    """A Line's Processors slice (line.go:17) fused on the device; takes ownership."""
+
+    def __init__(self, stages: Sequence[Processor]):
+        s0 = stages[0]
+        super().__init__(s0.buffer_size, s0.channels, dtype=s0.dtype, device=s0.device,
+                         lines=s0.lines, max_batch=s0.max_batch)
+        arr = (C.c_void_p * len(stages))(*[s._h.value for s in stages])
+        self._created(L.lib().pipe_hip_chain_create(arr, len(stages), C.byref(self._h)),
+                      "chain_create")
+        for s in stages:
+            s._owned = True
+        self.stages = list(stages)
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    L.lib().pipe_hip_device_count(C.byref(n))
+    return n.value
+
+
+def synth_fill(d_out, seed: int, first_index: int = 0, device: Optional[int] = None, stream: int = 0):
+    """Fill a torch device tensor with the SplitMix64 synthetic stream."""
+    import torch
+    dt = L.F64 if d_out.dtype == torch.float64 else L.F32
+    dev = d_out.device.index if device is None else device
+    L.check(L.lib().pipe_hip_synth_fill(dev or 0, _devptr(d_out), dt, C.c_uint64(seed),
+                                        int(first_index), d_out.numel(), C.c_void_p(stream or None)),
+            "synth_fill")

@@ -1,0 +1,392 @@
+"""Parity of the HIP Processors (through the C ABI) against the CPU oracle on the
+same seeded inputs.  The bar (north_star: <= 1 ULP float32) is met with margin:
+  float64 buffers : bit-exact
+  float32 buffers : bit-exact against (float)oracle_f64, i.e. correctly rounded
+because kernels and oracle share one arithmetic contract (oracle/dsp_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P = None
+torch = None
+
+
+def setup_module(module):
+    global P, torch
+    import torch as _t
+    from pipe_amd import processors as _p
+    assert _t.cuda.is_available(), "-m gpu tests need a GPU; refusing to pass silently"
+    P, torch = _p, _t
+
+
+DTYPES = [np.float32, np.float64]
+
+
+def sig(seed, frames, channels, dtype):
+    """SplitMix64 synthetic samples: exact in f32, so both dtypes see the same values."""
+    return synth.samples(synth.line_seed(seed), 0, frames * channels).reshape(frames, channels).astype(dtype)
+
+
+def expect(y64, dtype):
+    return np.asarray(y64, dtype=np.float64).astype(dtype)
+
+
+def ragged(total, pieces):
+    cuts = [0] + list(pieces)
+    acc, out = 0, []
+    for p in pieces:
+        out.append((acc, min(acc + p, total)))
+        acc += p
+    assert acc >= total
+    return [(a, b) for a, b in out if a < total or a == b]
+
+
+# ------------------------------------------------------------------ copy / gain
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("data", [[1, 1, 1, 1], [1, 1, 1, 1, 2, 2, 2, 2]])
+def test_copy_known_answer_from_reference(dtype, data):
+    # TestProcessor mock_test.go:133-146 (Channels: 1)
+    x = np.array(data, dtype=dtype).reshape(-1, 1)
+    with P.Copy(len(data), 1, dtype=dtype) as p:
+        p.start()
+        assert np.array_equal(p.process(x), x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("g", [1.0, 0.5, 0.7071067811865476, -3.0])
+@pytest.mark.parametrize("channels,frames", [(1, 512), (2, 4096), (8, 333), (3, 1)])
+def test_gain(dtype, g, channels, frames):
+    x = sig(1, frames, channels, dtype)
+    with P.Gain(g, 4096, channels, dtype=dtype) as p:
+        p.start()
+        got = p.process(x)
+    assert np.array_equal(got, expect(O.gain(x.astype(np.float64), g), dtype))
+
+
+def test_gain_empty_and_mutation():
+    with P.Gain(2.0, 512, 2) as p:
+        p.start()
+        assert p.process(np.zeros((0, 2), np.float32)).shape == (0, 2)
+        x = sig(2, 512, 2, np.float32)
+        a = p.process(x)
+        p.set_gain(0.25)  # mutation applied between buffers (pipe.go:433)
+        b = p.process(x)
+    assert np.array_equal(a, x * 2) and np.array_equal(b, x * 0.25)
+
+
+# ------------------------------------------------------------------ FIR
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("channels", [1, 2, 3, 8])
+@pytest.mark.parametrize("ntaps", [1, 2, 17, 256, 300])
+def test_fir_streaming_bit_exact(dtype, channels, ntaps):
+    F = 1024
+    h = synth.fir_lowpass_taps(ntaps) if ntaps > 2 else np.array([0.75, -0.5][:ntaps])
+    # buffers: full, short-than-history, empty, full, short last (pipe.go:441-443)
+    lens = [F, 7, 0, F, 100, F, 513]
+    x = sig(3, sum(lens), channels, dtype)
+    ref = O.Fir(h, channels)
+    with P.Fir(h, F, channels, dtype=dtype) as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n])
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(n, channels), dtype)
+            assert got.shape == (n, channels)
+            assert np.array_equal(got, want), f"buffer at {pos} len {n}"
+            pos += n
+        # StartFunc resets history (pipe_test.go:108-131: a pipe can be restarted)
+        p.start()
+        ref.reset()
+        got = p.process(x[:F])
+        assert np.array_equal(got, expect(ref.process(x[:F].astype(np.float64)).reshape(F, channels), dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fir_config2_4096x2_256taps(dtype):
+    # BASELINE config[1]: 1 Line, 2 ch, 4096-frame buffers, 256 taps
+    F, C, N = 4096, 2, 256
+    h = synth.fir_lowpass_taps(N, f32_rounded=(dtype == np.float32))
+    x = sig(0, 4 * F, C, dtype)
+    ref = O.Fir(h, C)
+    with P.Fir(h, F, C, dtype=dtype) as p:
+        p.start()
+        for k in range(4):
+            got = p.process(x[k * F:(k + 1) * F])
+            want = expect(ref.process(x[k * F:(k + 1) * F].astype(np.float64)).reshape(F, C), dtype)
+            assert np.array_equal(got, want)
+
+
+def test_fir_impulse_response_is_taps():
+    h = synth.fir_lowpass_taps(256)
+    x = np.zeros((1024, 2), np.float64)
+    x[3, 0] = 1.0
+    x[700, 1] = -2.0
+    with P.Fir(h, 1024, 2, dtype=np.float64) as p:
+        p.start()
+        y = p.process(x)
+    assert np.array_equal(y[3:259, 0], h)
+    assert np.array_equal(y[700:956, 1], -2.0 * h)
+    assert np.all(y[:3, 0] == 0) and np.all(y[:700, 1] == 0)
+
+
+def test_fir_taps_mutation_affects_next_buffer_only():
+    F, C = 512, 2
+    h1, h2 = synth.fir_lowpass_taps(64), synth.fir_lowpass_taps(64, fc=0.1)
+    x = sig(4, 3 * F, C, np.float64)
+    ref = O.Fir(h1, C)
+    with P.Fir(h1, F, C, dtype=np.float64) as p:
+        p.start()
+        a = p.process(x[:F])
+        p.set_taps(h2)
+        b = p.process(x[F:2 * F])
+        c = p.process(x[2 * F:])
+    wa = ref.process(x[:F])
+    ref.set_taps(h2)  # history is kept, only coefficients change
+    wb = ref.process(x[F:2 * F])
+    wc = ref.process(x[2 * F:])
+    assert np.array_equal(a, wa) and np.array_equal(b, wb) and np.array_equal(c, wc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fir_batch_equals_buffer_by_buffer(dtype):
+    # 3 Lines x 5 consecutive buffers in one device-resident launch == 15 calls
+    L_, K, F, C, N = 3, 5, 1024, 2, 256
+    h = synth.fir_lowpass_taps(N)
+    x = np.stack([sig(10 + l, 2 * K * F, C, dtype) for l in range(L_)])  # (L, 2KF, C)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    with P.Fir(h, F, C, dtype=dtype, lines=L_, max_batch=K) as p:
+        p.start()
+        outs = []
+        for half in range(2):  # two batch calls: state must carry between them
+            xin = np.ascontiguousarray(x[:, half * K * F:(half + 1) * K * F])
+            d_in = torch.from_numpy(xin).cuda()
+            d_out = torch.empty_like(d_in)
+            p.process_batch(d_in, d_out, K * F)
+            torch.cuda.synchronize()
+            outs.append(d_out.cpu().numpy())
+        got = np.concatenate(outs, axis=1)
+        assert "fir_direct_kernel" in p.kernel_name()
+    for l in range(L_):
+        ref = O.Fir(h, C)
+        want = np.concatenate([expect(ref.process(x[l, k * F:(k + 1) * F].astype(np.float64)).reshape(F, C), dtype)
+                               for k in range(2 * K)])
+        assert np.array_equal(got[l], want), f"line {l}"
+
+
+def test_fir_full_size_properties():
+    # BASELINE-size stream (1 Line, 2 ch, 256 buffers of 4096 frames, f32): checked
+    # through size-independent properties instead of a CPU run of the whole stream:
+    #  (a) splitting the stream into two launches changes nothing (state carry);
+    #  (b) a spot-checked window equals the oracle run on just that window + history;
+    #  (c) a delayed unit impulse reproduces the taps at the far end of the stream.
+    F, C, N, K = 4096, 2, 256, 256
+    h = synth.fir_lowpass_taps(N, f32_rounded=True)
+    n = K * F * C
+    d_in = torch.empty(n, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(0))
+    host = d_in.cpu().numpy().reshape(K * F, C)
+    assert np.array_equal(host[:1000].ravel(), synth.samples(synth.line_seed(0), 0, 2000, np.float32))
+    whole = torch.empty_like(d_in)
+    with P.Fir(h, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        p.process_batch(d_in, whole, K * F)
+        p.start()
+        split = torch.empty_like(d_in)
+        cut = 100 * F + 0
+        p.process_batch(d_in[:cut * C], split[:cut * C], cut)
+        p.process_batch(d_in[cut * C:], split[cut * C:], K * F - cut)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, split)
+        w = whole.cpu().numpy().reshape(K * F, C)
+        for start in (0, 5 * F - 3, K * F - 3000):
+            a = max(0, start - (N - 1))
+            ref = O.Fir(h, C)
+            want = ref.process(host[a:start + 2000].astype(np.float64)).reshape(-1, C)[start - a:]
+            assert np.array_equal(w[start:start + 2000], want.astype(np.float32)), start
+        imp = torch.zeros(n, dtype=torch.float32, device="cuda")
+        pos = K * F - 300
+        imp[pos * C + 1] = 1.0
+        out = torch.empty_like(imp)
+        p.start()
+        p.process_batch(imp, out, K * F)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().reshape(K * F, C)
+        assert np.array_equal(o[pos:pos + 256, 1], h.astype(np.float32))
+        assert not o[:, 0].any() and not o[:pos, 1].any()
+
+
+# ------------------------------------------------------------------ biquad
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("channels", [1, 2, 8])
+@pytest.mark.parametrize("sections", [1, 2])
+def test_biquad_streaming_bit_exact(dtype, channels, sections):
+    F = 1024
+    q = synth.biquad_rbj_lowpass()
+    if sections == 2:
+        q = np.vstack([q, synth.biquad_rbj_lowpass(fc=4000.0, q=1.3)])
+    lens = [F, 1, 0, F, 130, 777]
+    x = sig(5, sum(lens), channels, dtype)
+    ref = O.Biquad(q, channels)
+    with P.Biquad(q, F, channels, dtype=dtype) as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n])
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(n, channels), dtype)
+            assert np.array_equal(got, want), (pos, n)
+            pos += n
+
+
+def test_biquad_many_lines_batch():
+    L_, F, C, K = 70, 512, 8, 2  # 560 series: several lanes per workgroup
+    q = synth.biquad_rbj_lowpass()
+    x = np.stack([sig(100 + l, K * F, C, np.float32) for l in range(L_)])
+    with P.Biquad(q, F, C, dtype=np.float32, lines=L_, max_batch=K) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        p.process_batch(d_in, d_out, K * F)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+    for l in (0, 1, 33, 69):
+        want = O.Biquad(q, C).process(x[l].astype(np.float64)).reshape(K * F, C).astype(np.float32)
+        assert np.array_equal(got[l], want), l
+
+
+# ------------------------------------------------------------------ resampler
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("up,down", [(160, 147), (147, 160), (2, 1), (1, 3)])
+def test_resampler_streaming_bit_exact(dtype, up, down):
+    C, T, F = 2, 24, 1024
+    proto = synth.resampler_proto(up, down, T)
+    lens = [F, 3, 0, 500, F, 17]
+    x = sig(6, sum(lens), C, dtype)
+    ref = O.Resampler(proto, T, up, down, C)
+    cap = -(-F * up // down) + 1
+    with P.Resampler(proto, T, up, down, F, C, dtype=dtype) as p:
+        assert p.output_properties() == (C, up, down)
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n], out_cap_frames=cap)
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(-1, C), dtype)
+            assert got.shape == want.shape, (pos, n)
+            assert np.array_equal(got, want), (pos, n)
+            pos += n
+
+
+def test_resampler_config5_capacity_contract():
+    # 4096 frames @44.1k -> 4459 @48k cannot fit ProcessFunc's 4096-frame out
+    from pipe_amd._lib import ECAP, PipeHipError
+    T, up, down, F, C = 24, 160, 147, 4096, 2
+    proto = synth.resampler_proto(up, down, T)
+    x = sig(7, F, C, np.float32)
+    with P.Resampler(proto, T, up, down, F, C) as p:
+        p.start()
+        with pytest.raises(PipeHipError) as e:
+            p.process(x, out_cap_frames=F)
+        assert e.value.status == ECAP
+        # nothing was consumed: a 3763-frame buffer now fills the 4096-frame out exactly
+        got = p.process(x[:3763], out_cap_frames=F)
+        want = O.Resampler(proto, T, up, down, C).process(x[:3763].astype(np.float64)).reshape(-1, C)
+        assert got.shape == (4096, C) and np.array_equal(got, want.astype(np.float32))
+
+
+# ------------------------------------------------------------------ mix, chain
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_in", [2, 3])
+def test_mix(dtype, n_in):
+    F, C = 4096, 2
+    xs = [sig(20 + i, F, C, dtype) for i in range(n_in)]
+    with P.Mix(n_in, F, C, dtype=dtype) as p:
+        p.start()
+        got = p.process(xs)
+    want = O.mix([x.astype(np.float64) for x in xs]).astype(dtype)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_chain_fir_biquad_gain_config4(dtype):
+    # BASELINE config[3] stage chain: FIR + biquad + gain, 8 channels; f64
+    # intermediates, one rounding at the end for f32 buffers
+    F, C, N = 2048, 8, 256
+    h = synth.fir_lowpass_taps(N)
+    q = synth.biquad_rbj_lowpass()
+    g = 0.7071067811865476
+    lens = [F, F, 300]
+    x = sig(8, sum(lens), C, dtype)
+    kw = dict(dtype=dtype)
+    chain = P.Chain([P.Fir(h, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(g, F, C, **kw)])
+    rf, rb = O.Fir(h, C), O.Biquad(q, C)
+    with chain as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n])
+            want = O.gain(rb.process(rf.process(x[pos:pos + n].astype(np.float64))), g)
+            assert np.array_equal(got, expect(want.reshape(n, C), dtype)), pos
+            pos += n
+
+
+def test_chain_matches_oracle_pipe_loop():
+    # the same chain driven by the oracle's restatement of pipe.Run (pipe.go:90-103)
+    F, C = 512, 2
+    frames = 5 * F + 123
+    h = synth.fir_lowpass_taps(33)
+    q = synth.biquad_rbj_lowpass()
+    x = sig(9, frames, C, np.float64)
+    line = O.Line(limit=frames, channels=C, src_kind=O.SRC_ARRAY, data=x.ravel(), discard=False,
+                  procs=[O.Proc(O.PROC_FIR, h), O.Proc(O.PROC_BIQUAD, q), O.Proc(O.PROC_GAIN, [0.5])])
+    err, res = O.run_lines(F, [line])
+    assert err.ok and res[0].sink.messages == 6
+    kw = dict(dtype=np.float64)
+    with P.Chain([P.Fir(h, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.5, F, C, **kw)]) as p:
+        p.start()
+        got = np.concatenate([p.process(x[a:a + F]) for a in range(0, frames, F)])
+    assert np.array_equal(got.ravel(), res[0].values)
+
+
+# ------------------------------------------------------------------ async form, errors
+def test_submit_collect_depth_one():
+    from pipe_amd._lib import ESTATE, PipeHipError
+    F, C = 1024, 2
+    h = synth.fir_lowpass_taps(64)
+    x = sig(11, 4 * F, C, np.float32)
+    ref = O.Fir(h, C)
+    with P.Fir(h, F, C) as p:
+        p.start()
+        with pytest.raises(PipeHipError) as e:
+            p.collect()
+        assert e.value.status == ESTATE
+        for k in range(4):
+            p.submit(x[k * F:(k + 1) * F])
+            if k == 0:
+                with pytest.raises(PipeHipError) as e:
+                    p.submit(x[:F])  # capacity 1, like fitting.Async (fitting.go:56-60)
+                assert e.value.status == ESTATE
+            got = p.collect()
+            want = ref.process(x[k * F:(k + 1) * F].astype(np.float64)).reshape(F, C).astype(np.float32)
+            assert np.array_equal(got, want)
+
+
+def test_argument_errors():
+    from pipe_amd._lib import EINVAL, ENODEV, PipeHipError
+    with pytest.raises(PipeHipError) as e:
+        P.Fir([], 512, 2)
+    assert e.value.status == EINVAL
+    with pytest.raises(PipeHipError) as e:
+        P.Gain(1.0, 512, 2, device=99)
+    assert e.value.status == ENODEV
+    with pytest.raises(PipeHipError) as e:
+        P.Gain(1.0, 0, 2)
+    assert e.value.status == EINVAL
+    with P.Gain(1.0, 512, 2) as p:
+        p.start()
+        with pytest.raises(PipeHipError) as e:
+            p.process(np.zeros((513, 2), np.float32))  # in_frames > bufferSize
+        assert e.value.status == EINVAL
