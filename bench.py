@@ -197,7 +197,7 @@ def main():
                       f"oracle restatement of pipe.Run (sync, 1 thread), {cb['seconds']:.1f} s",
         }
         ncpu = os.cpu_count() or 1
-        per = max(8, args.cpu_buffers // 4)
+        per = max(8, args.cpu_buffers // 16)
         cbm = O.cpu_baseline(lines=ncpu, channels=C, frames=F, buffers=per, ntaps=N, threads=ncpu)
         result["cpu_baseline_all_cores"] = {
             "value": round(cbm["msamples_per_s"], 4), "unit": "Msamples/s", "cores": ncpu, "kind": "port",

@@ -17,6 +17,8 @@
 //   * results go back through LDS so the global store is fully coalesced.
 // The kernel is bound by the f64 VALU rate (2*N flop per scalar sample against
 // 8 B of HBM traffic): DESIGN.md "Roofline".
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -37,6 +39,8 @@ struct FirArgs {
     int TF;              // frames per tile = FB*R
     int plane;           // padded plane length (elements)
     int nfull, rem;      // N = nfull*R + rem
+    int cx_log;          // log2 of the staging column count (2^cx_log >= CG)
+    int ablate;          // tuning only (PIPE_HIP_FIR_ABLATE): 1 = skip staging loads, 2 = skip taps
 };
 
 // Taps are wave-uniform and immutable during a launch: reading them through the
@@ -89,19 +93,52 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
 
     // ---- stage [t0-HP, t0+TF) x cg channels into per-channel planes --------
-    const int nstage = (a.TF + a.HP) * cg;
-    for (int i = threadIdx.x; i < nstage; i += kThreads) {
-        const int f = i / cg;
-        const int cl = i - f * cg;
-        const int64_t g = t0 - a.HP + f;
+    // lane -> (channel tx, frame row ty) by shifts (CX = 2^cx_log >= cg); kUnroll
+    // independent loads are issued before the first is consumed, so a wave keeps
+    // kUnroll HBM/L2 requests in flight instead of one.
+    const int cx_log = a.cx_log;
+    const int tx = threadIdx.x & ((1 << cx_log) - 1);
+    const int ty = threadIdx.x >> cx_log;
+    const int FY = kThreads >> cx_log;
+    const bool tx_ok = tx < cg;
+    const int nfr = a.TF + a.HP;
+    // frames f < nh precede this call: history (or zeros before it)
+    const int64_t nh64 = (int64_t)a.HP - t0;
+    const int nh = nh64 > 0 ? (int)nh64 : 0;
+    for (int f = ty; f < nh; f += FY) {
+        const int64_t g = t0 - a.HP + f;  // < 0
         double v = 0.0;
-        if (g >= 0) {
-            if (g < a.frames)
-                v = (double)in[g * a.C + c0 + cl];
-        } else if (g >= -(int64_t)a.H) {
-            v = hist[(g + a.H) * a.C + c0 + cl];
+        if (tx_ok && g >= -(int64_t)a.H)
+            v = hist[(g + a.H) * a.C + c0 + tx];
+        if (tx_ok)
+            xs[tx * a.plane + pad_index<R>(f)] = v;
+    }
+    {
+        constexpr int kUnroll = 8;
+        const int64_t last = a.frames - 1;
+        // lanes beyond the channel group read channel 0 and discard it: keeps the
+        // loads unconditional so that they can all be issued before the first wait
+        const TIn *__restrict__ src = in + c0 + (tx_ok ? tx : 0);
+        // first row >= nh that this lane owns
+        int f0 = ty;
+        if (f0 < nh)
+            f0 += ((nh - f0 + FY - 1) / FY) * FY;
+        for (int fb = f0; fb < nfr && !(a.ablate & 1); fb += kUnroll * FY) {
+            TIn v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                int64_t g = t0 - a.HP + fb + u * FY;
+                g = g > last ? last : g;  // clamped: the value is discarded below
+                v[u] = src[g * a.C];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int f = fb + u * FY;
+                const int64_t g = t0 - a.HP + f;
+                if (tx_ok && f < nfr)
+                    xs[tx * a.plane + pad_index<R>(f)] = g <= last ? (double)v[u] : 0.0;
+            }
         }
-        xs[cl * a.plane + pad_index<R>(f)] = v;
     }
     __syncthreads();
 
@@ -177,13 +214,11 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 }
             }
             __syncthreads();
-            const int nout = a.TF * cg;
-            for (int i = threadIdx.x; i < nout; i += kThreads) {
-                const int f = i / cg;
-                const int c = i - f * cg;
+            for (int f = ty; f < a.TF; f += FY) {
                 const int64_t g = t0 + f;
-                if (g < a.frames)
-                    out[g * a.C + c0 + c] = os[i + (i >> 5)];
+                const int i = f * cg + tx;
+                if (tx_ok && g < a.frames)
+                    out[g * a.C + c0 + tx] = os[i + (i >> 5)];
             }
         } else if (active) {
 #pragma unroll
@@ -285,6 +320,16 @@ public:
         a.plane = g.plane;
         a.nfull = N_ / g.R;
         a.rem = N_ % g.R;
+        a.cx_log = 0;
+        if (const char *ab = std::getenv("PIPE_HIP_FIR_ABLATE")) {
+            a.ablate = std::atoi(ab);
+            if (a.ablate & 2) {
+                a.nfull = 0;
+                a.rem = 0;
+            }
+        }
+        while ((1 << a.cx_log) < g.CG)
+            ++a.cx_log;
         const dim3 grid((unsigned)((frames + g.TF - 1) / g.TF), (unsigned)cfg.lines,
                         (unsigned)((cfg.channels + g.CG - 1) / g.CG));
         PH_TRY(timer.begin(s));
@@ -339,7 +384,12 @@ private:
     {
         static const int Rs[] = {16, 8, 4, 2, 1};
         bool have = false;
+        // tuning knob for experiments: PIPE_HIP_FIR_R pins the register blocking
+        const char *force = std::getenv("PIPE_HIP_FIR_R");
+        const int forced = force ? std::atoi(force) : 0;
         for (int R : Rs) {
+            if (forced && R != forced)
+                continue;
             Geometry g;
             int split = 1;
             bool ok = geometry(R, split, &g);
