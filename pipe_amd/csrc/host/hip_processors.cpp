@@ -1,0 +1,162 @@
+#include "hip_processors.hpp"
+
+#include <string>
+
+#include "pipe_hip.h"
+
+namespace pipe {
+namespace hip {
+
+error StatusError(int status, const char *what)
+{
+    if (status == PIPE_HIP_OK)
+        return nullptr;
+    std::string m = std::string("pipe_hip ") + what + ": " + pipe_hip_strerror(status);
+    if (status == PIPE_HIP_EHIP)
+        m += " (hipError " + std::to_string(pipe_hip_last_hip_error()) + ")";
+    return NewError(m);
+}
+
+Handle::~Handle()
+{
+    if (p_)
+        pipe_hip_destroy(p_);
+}
+
+mut::MutatorFunc Handle::SetGain(double g)
+{
+    pipe_hip_processor *p = p_;
+    return [p, g]() -> error { return StatusError(pipe_hip_set_param(p, PIPE_HIP_PARAM_GAIN, &g, 1), "set gain"); };
+}
+
+mut::MutatorFunc Handle::SetTaps(std::vector<double> taps)
+{
+    pipe_hip_processor *p = p_;
+    return [p, taps]() -> error {
+        return StatusError(pipe_hip_set_param(p, PIPE_HIP_PARAM_TAPS, taps.data(), (int32_t)taps.size()), "set taps");
+    };
+}
+
+mut::MutatorFunc Handle::SetCoeffs(std::vector<double> coeffs)
+{
+    pipe_hip_processor *p = p_;
+    return [p, coeffs]() -> error {
+        return StatusError(pipe_hip_set_param(p, PIPE_HIP_PARAM_COEFFS, coeffs.data(), (int32_t)coeffs.size()),
+                           "set coeffs");
+    };
+}
+
+void UsePinnedPools() { signal::SetPinnedAllocator(pipe_hip_host_alloc, pipe_hip_host_free); }
+
+namespace {
+
+pipe_hip_config make_cfg(const Options &o, int bufferSize, const SignalProperties &in)
+{
+    pipe_hip_config c{};
+    c.device = o.device;
+    c.buffer_size = bufferSize;
+    c.channels = in.Channels;
+    c.dtype = PIPE_HIP_F64;  // the reference pipe carries float64 (pipe.go:394,437)
+    c.lines = 1;
+    c.max_batch = 1;
+    return c;
+}
+
+// fill the Processor's hooks from a created handle
+error finish(pipe_hip_processor *raw, const SignalProperties &input, Processor *out,
+             std::shared_ptr<Handle> *handle)
+{
+    auto h = std::make_shared<Handle>(raw);
+    if (handle)
+        *handle = h;
+    int32_t ch = 0, up = 1, down = 1;
+    if (error e = StatusError(pipe_hip_output_properties(raw, &ch, &up, &down), "output_properties"))
+        return e;
+    out->SignalProperties = SignalProperties{input.SampleRate * up / down, ch};
+    out->StartFunc = [h](const Context &) -> error { return StatusError(pipe_hip_start(h->get()), "start"); };
+    out->FlushFunc = [h](const Context &) -> error { return StatusError(pipe_hip_flush(h->get()), "flush"); };
+    out->ProcessFunc = [h](const signal::Floating &in, signal::Floating &o, int *n) -> error {
+        int32_t written = 0;
+        const int st = pipe_hip_process(h->get(), in.data(), in.Length(), o.data(), o.Length(), &written);
+        if (st != PIPE_HIP_OK)
+            return StatusError(st, "process");
+        *n = written;
+        return nullptr;
+    };
+    return nullptr;
+}
+
+}  // namespace
+
+ProcessorAllocatorFunc Gain(double gain, Options o, std::shared_ptr<Handle> *handle)
+{
+    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+        pipe_hip_processor *raw = nullptr;
+        if (error e = StatusError(pipe_hip_gain_create(&c, gain, &raw), "gain_create"))
+            return e;
+        return finish(raw, input, out, handle);
+    };
+}
+
+ProcessorAllocatorFunc Copy(Options o, std::shared_ptr<Handle> *handle) { return Gain(1.0, o, handle); }
+
+ProcessorAllocatorFunc Fir(std::vector<double> taps, Options o, std::shared_ptr<Handle> *handle)
+{
+    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+        pipe_hip_processor *raw = nullptr;
+        if (error e = StatusError(pipe_hip_fir_create(&c, taps.data(), (int32_t)taps.size(), &raw), "fir_create"))
+            return e;
+        return finish(raw, input, out, handle);
+    };
+}
+
+ProcessorAllocatorFunc Biquad(std::vector<double> coeffs, Options o, std::shared_ptr<Handle> *handle)
+{
+    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+        pipe_hip_processor *raw = nullptr;
+        if (error e = StatusError(pipe_hip_biquad_create(&c, coeffs.data(), (int32_t)(coeffs.size() / 5), &raw),
+                                  "biquad_create"))
+            return e;
+        return finish(raw, input, out, handle);
+    };
+}
+
+ProcessorAllocatorFunc Chain(std::vector<StageSpec> stages, Options o, std::shared_ptr<Handle> *handle)
+{
+    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+        std::vector<pipe_hip_processor *> raws;
+        auto cleanup = [&raws]() {
+            for (auto *r : raws)
+                pipe_hip_destroy(r);
+        };
+        for (const StageSpec &s : stages) {
+            pipe_hip_processor *raw = nullptr;
+            int st = PIPE_HIP_EINVAL;
+            if (s.kind == StageSpec::kGain && s.params.size() == 1)
+                st = pipe_hip_gain_create(&c, s.params[0], &raw);
+            else if (s.kind == StageSpec::kFir)
+                st = pipe_hip_fir_create(&c, s.params.data(), (int32_t)s.params.size(), &raw);
+            else if (s.kind == StageSpec::kBiquad)
+                st = pipe_hip_biquad_create(&c, s.params.data(), (int32_t)(s.params.size() / 5), &raw);
+            if (st != PIPE_HIP_OK) {
+                cleanup();
+                return StatusError(st, "chain stage create");
+            }
+            raws.push_back(raw);
+        }
+        pipe_hip_processor *chain = nullptr;
+        const int st = pipe_hip_chain_create(raws.data(), (int32_t)raws.size(), &chain);
+        if (st != PIPE_HIP_OK) {
+            cleanup();
+            return StatusError(st, "chain_create");
+        }
+        return finish(chain, input, out, handle);
+    };
+}
+
+}  // namespace hip
+}  // namespace pipe

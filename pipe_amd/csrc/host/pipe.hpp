@@ -1,0 +1,232 @@
+// Host-side mirror of the reference's operator API for the Processor-stage hot
+// path (Go toolchain absent here, so the host side above the C ABI is C++):
+//
+//   pipe::Line{Source, Processors, Sink}  + *AllocatorFunc      line.go:14-35
+//   pipe::SignalProperties                                      line.go:38-41
+//   pipe::Source / Processor / Sink + *Func hook types          pipe.go:32-87
+//   pipe::Run(ctx, bufferSize, lines...)   (sync, one thread)   pipe.go:89-103
+//   pipe::New(bufferSize, lines...) -> Pipe::Start / Wait /Push pipe.go:105-126,197-257
+//   executors, sync/async fittings, mutations                   run.go, fitting.go, mutable.go
+//
+// Same names, argument meaning and error behaviour as the reference, so that the
+// tests read like pipe_test.go.  Live graph edits (AddLine / InsertProcessor,
+// pipe.go:260-365) are out of scope.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "signal.hpp"
+
+namespace pipe {
+
+// ---- errors (Go `error` values) ---------------------------------------------
+struct ErrorValue {
+    std::string msg;
+    std::shared_ptr<const ErrorValue> cause;  // %w
+};
+using error = std::shared_ptr<const ErrorValue>;  // nullptr == nil
+error NewError(const std::string &msg);
+error Wrap(const std::string &prefix, const error &cause);  // fmt.Errorf("prefix: %w", cause)
+bool Is(const error &err, const error &target);             // errors.Is
+std::string ErrorString(const error &err);
+namespace io {
+const error &EOF_();  // io.EOF sentinel (graceful end of stream)
+}
+
+// ErrorRun{ErrExec, ErrFlush}                                    error.go:11-39
+struct ErrorRun {
+    error ErrExec;
+    error ErrFlush;
+};
+
+// ---- context.Context (cancellation only) ----------------------------------------
+class Context {
+public:
+    Context() : done_(std::make_shared<std::atomic<bool>>(false)) {}
+    static Context Background() { return Context(); }
+    bool Done() const { return done_->load(std::memory_order_acquire); }
+    void Cancel() const { done_->store(true, std::memory_order_release); }
+
+private:
+    std::shared_ptr<std::atomic<bool>> done_;
+};
+
+// ---- mutable (in-band parameter changes)                    mutable/mutable.go ----
+namespace mut {
+using MutatorFunc = std::function<error()>;
+struct Context {  // 16 random bytes; all-zero == immutable     mutable.go:12,28-37
+    uint64_t hi = 0, lo = 0;
+    bool IsMutable() const { return hi != 0 || lo != 0; }
+    bool operator<(const Context &o) const { return hi != o.hi ? hi < o.hi : lo < o.lo; }
+    bool operator==(const Context &o) const { return hi == o.hi && lo == o.lo; }
+};
+Context Mutable();
+inline Context Immutable() { return Context{}; }
+struct Mutation {  // mutable.go:15-18,40-58
+    Context ctx;
+    MutatorFunc mutator;
+    void Apply() const
+    {
+        if (mutator)
+            mutator();
+    }
+};
+Mutation Mutate(const Context &c, MutatorFunc m);  // throws std::logic_error on immutable
+// Mutations: Context -> queued mutators; nullptr == nil map      mutable.go:21,61-122
+class Mutations {
+public:
+    bool nil() const { return !map_; }
+    Mutations &Put(const Mutation &m);
+    error ApplyTo(const Context &id);  // runs and deletes this component's mutators
+    Mutations &Append(const Mutations &src);
+    Mutations Detach(const Context &id);
+    size_t size() const { return map_ ? map_->size() : 0; }
+
+private:
+    std::shared_ptr<std::map<Context, std::vector<MutatorFunc>>> map_;
+};
+}  // namespace mut
+
+// ---- fitting (stage-to-stage transport)          internal/fitting/fitting.go ----
+namespace fitting {
+struct Message {  // fitting.go:11-15
+    signal::Floating Signal;
+    mut::Mutations Mutations;
+};
+class Fitting {  // fitting.go:17-36
+public:
+    virtual ~Fitting() = default;
+    virtual bool Send(const Context &ctx, Message m) = 0;
+    virtual Message Receive(const Context &ctx, bool *ok) = 0;
+    virtual void Close() = 0;
+};
+using New = std::function<std::shared_ptr<Fitting>()>;
+std::shared_ptr<Fitting> Sync();   // one slot + closed flag      fitting.go:62-79
+std::shared_ptr<Fitting> Async();  // channel of capacity 1       fitting.go:81-104
+}  // namespace fitting
+
+// ---- components ------------------------------------------------------------------
+struct SignalProperties {  // line.go:38-41
+    signal::Frequency SampleRate = 0;
+    int Channels = 0;
+};
+
+using SourceFunc = std::function<error(signal::Floating &out, int *read)>;                       // pipe.go:47
+using ProcessFunc = std::function<error(const signal::Floating &in, signal::Floating &out, int *n)>;  // pipe.go:64
+using SinkFunc = std::function<error(const signal::Floating &in)>;                               // pipe.go:80
+using StartFunc = std::function<error(const Context &)>;                                         // pipe.go:83
+using FlushFunc = std::function<error(const Context &)>;                                         // pipe.go:86
+
+struct out_link {  // line.go:51-54
+    std::shared_ptr<fitting::Fitting> sender;
+    std::shared_ptr<signal::PoolAllocator> allocator;
+};
+struct in_link {  // line.go:56-59
+    std::shared_ptr<fitting::Fitting> receiver;
+    std::shared_ptr<signal::PoolAllocator> allocator;
+    void insert(const out_link &o)  // line.go:155-158
+    {
+        receiver = o.sender;
+        allocator = o.allocator;
+    }
+};
+
+// executor interface                                               run.go:13-18
+class executor {
+public:
+    virtual ~executor() = default;
+    virtual error execute(const Context &ctx) = 0;
+    virtual error startHook(const Context &ctx) = 0;
+    virtual error flushHook(const Context &ctx) = 0;
+};
+
+using Destination = std::shared_ptr<struct MutationChan>;  // mutable.Destination (chan cap 1)
+
+struct Source : executor {  // pipe.go:35-43
+    Destination dest;
+    mut::Context Context;
+    ::pipe::SourceFunc SourceFunc;
+    ::pipe::StartFunc StartFunc;
+    ::pipe::FlushFunc FlushFunc;
+    ::pipe::SignalProperties SignalProperties;
+    out_link out;
+    void connect(int bufferSize, const fitting::New &fn);  // pipe.go:372-377
+    error execute(const ::pipe::Context &ctx) override;     // pipe.go:379-413
+    error startHook(const ::pipe::Context &ctx) override;
+    error flushHook(const ::pipe::Context &ctx) override;
+};
+
+struct Processor : executor {  // pipe.go:52-60
+    mut::Context Context;
+    ::pipe::ProcessFunc ProcessFunc;
+    ::pipe::StartFunc StartFunc;
+    ::pipe::FlushFunc FlushFunc;
+    ::pipe::SignalProperties SignalProperties;
+    in_link in;
+    out_link out;
+    void connect(int bufferSize, const fitting::New &fn, const out_link &prev);  // pipe.go:415-421
+    error execute(const ::pipe::Context &ctx) override;                          // pipe.go:423-451
+    error startHook(const ::pipe::Context &ctx) override;
+    error flushHook(const ::pipe::Context &ctx) override;
+};
+
+struct Sink : executor {  // pipe.go:69-76
+    mut::Context Context;
+    ::pipe::SinkFunc SinkFunc;
+    ::pipe::StartFunc StartFunc;
+    ::pipe::FlushFunc FlushFunc;
+    ::pipe::SignalProperties SignalProperties;
+    in_link in;
+    void connect(int bufferSize, const out_link &prev);  // pipe.go:453-455
+    error execute(const ::pipe::Context &ctx) override;  // pipe.go:457-471
+    error startHook(const ::pipe::Context &ctx) override;
+    error flushHook(const ::pipe::Context &ctx) override;
+};
+
+// allocators                                                       line.go:21-35
+using SourceAllocatorFunc = std::function<error(mut::Context mctx, int bufferSize, Source *out)>;
+using ProcessorAllocatorFunc =
+    std::function<error(mut::Context mctx, int bufferSize, SignalProperties input, Processor *out)>;
+using SinkAllocatorFunc = std::function<error(mut::Context mctx, int bufferSize, SignalProperties input, Sink *out)>;
+
+struct Line {  // line.go:14-19
+    mut::Context Context;
+    SourceAllocatorFunc Source;
+    std::vector<ProcessorAllocatorFunc> Processors;
+    SinkAllocatorFunc Sink;
+};
+
+inline std::vector<ProcessorAllocatorFunc> Processors(std::vector<ProcessorAllocatorFunc> p) { return p; }
+
+// pipe.Run: every Line in ONE thread, round robin                  pipe.go:89-103
+// Returns nil, a plain error ("error starting ..."), or an ErrorRun rendered as
+// an error whose cause chain keeps the original for Is().
+error Run(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail = nullptr);
+
+// pipe.New + Start + Wait: immutable Line context => one thread per component
+// connected by capacity-1 channels; mutable context => sync executor per context.
+class Pipe {
+public:
+    ~Pipe();
+    // Start returns a handle to Wait on                             pipe.go:197-214
+    std::shared_ptr<struct ErrChan> Start(const Context &ctx, std::vector<mut::Mutation> initializers = {});
+    void Push(std::vector<mut::Mutation> mutations);  // pipe.go:243-247 (before / between Starts)
+
+private:
+    friend error New(int, std::vector<Line>, std::unique_ptr<Pipe> *);
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+error New(int bufferSize, std::vector<Line> lines, std::unique_ptr<Pipe> *out);  // pipe.go:105-126
+error Wait(const std::shared_ptr<struct ErrChan> &errc);                          // pipe.go:249-257
+
+}  // namespace pipe

@@ -1,0 +1,192 @@
+"""The C++ host-side mirror of pipe.Run / pipe.New+Start+Wait (pipe_amd/csrc/host)
+against the reference's own known answers -- the same cases as
+tests/test_oracle_pipe.py, so product loop and oracle loop are both pinned to
+pipe_test.go / mock_test.go -- and, on the GPU, HIP Processors inside the loop
+against the oracle's loop."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import host as H
+from pipe_amd import synth
+
+BUF = 512  # pipe_test.go:17
+MODES = [H.MODE_RUN, H.MODE_ASYNC]
+
+
+def mock_line(limit, channels=1, procs=1, discard=True, value=0.0, **kw):
+    return H.Line(limit=limit, channels=channels, value=value, discard=discard,
+                  procs=[H.Proc(H.PROC_MOCK) for _ in range(procs)], **kw)
+
+
+def assert_line(res, messages, samples):
+    for c in [res.source, *res.procs, res.sink]:
+        assert (c.messages, c.samples) == (messages, samples)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("limit,messages", [(1040, 3), (1640, 4), (3048, 6), (4096, 8)])
+def test_short_last_buffer_counts(mode, limit, messages):
+    err, res = H.run(BUF, [mock_line(limit)], mode)  # pipe_test.go:337,363,394,399,404
+    assert not err.failed, err.message
+    assert_line(res[0], messages, limit)
+    assert res[0].source.flushed and res[0].procs[0].flushed and res[0].sink.flushed
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_three_lines(mode):
+    err, res = H.run(BUF, [mock_line(3048), mock_line(1640), mock_line(4096)], mode)  # pipe_test.go:385-436
+    assert not err.failed
+    assert_line(res[0], 6, 3048)
+    assert_line(res[1], 4, 1640)
+    assert_line(res[2], 8, 4096)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_simple_pipe_862_buffers(mode):
+    err, res = H.run(BUF, [mock_line(862 * BUF, channels=2)], mode)  # TestSimplePipe pipe_test.go:82-106
+    assert not err.failed
+    assert_line(res[0], 862, 862 * BUF)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_restart_doubles_sink_counts(mode):
+    err, res = H.run(BUF, [mock_line(862 * BUF, channels=2, procs=0)], mode, runs=2)  # TestReset pipe_test.go:108-131
+    assert not err.failed
+    assert (res[0].sink.messages, res[0].sink.samples) == (2 * 862, 2 * 862 * BUF)
+
+
+@pytest.mark.parametrize("limit,value,calls", [(11, 1.0, 3), (2500, 2.0, 500)])
+def test_mock_source_calls_and_constant_fill(limit, value, calls):
+    err, res = H.run(5, [mock_line(limit, channels=2, procs=1, value=value, discard=False)])  # mock_test.go:69-92
+    assert not err.failed
+    assert (res[0].source.messages, res[0].source.samples) == (calls, limit)
+    assert res[0].values.size == limit * 2 and np.all(res[0].values == value)
+
+
+@pytest.mark.parametrize("data", [[1, 1, 1, 1], [1, 1, 1, 1, 2, 2, 2, 2]])
+def test_mock_processor_identity(data):
+    x = np.array(data, dtype=np.float64)  # mock_test.go:133-146
+    line = H.Line(limit=x.size, channels=1, src_kind=H.SRC_ARRAY, data=x, procs=[H.Proc(H.PROC_MOCK)], discard=False)
+    err, res = H.run(x.size, [line])
+    assert not err.failed and np.array_equal(res[0].values, x)
+
+
+def test_hook_order_two_lines_processor_start_error():
+    l1 = mock_line(1040, discard=False)  # pipe_test.go:265-309
+    l2 = H.Line(limit=1040, channels=1, procs=[H.Proc(H.PROC_MOCK, err_on_start=True)], discard=False)
+    err, res = H.run(BUF, [l1, l2])
+    assert err.failed and err.is_mock_error and "error starting" in err.message
+    a, b = res
+    assert (a.source.started, a.procs[0].started, a.sink.started) == (True, True, True)
+    assert (a.source.flushed, a.procs[0].flushed, a.sink.flushed) == (True, True, True)
+    assert (b.source.started, b.procs[0].started, b.sink.started) == (True, True, False)
+    assert (b.source.flushed, b.procs[0].flushed, b.sink.flushed) == (True, False, False)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_processor_error_propagates_and_everything_is_flushed(mode):
+    line = H.Line(limit=1040, channels=1, procs=[H.Proc(H.PROC_MOCK, err_on_call=True)])  # pipe_test.go:437-457
+    err, res = H.run(BUF, [line], mode)
+    assert err.failed and err.is_mock_error and "error running" in err.message
+    r = res[0]
+    assert r.source.flushed and r.procs[0].flushed and r.sink.flushed
+
+
+@pytest.mark.parametrize("which", ["source", "processor", "sink"])
+def test_line_binding_fail(which):
+    line = mock_line(1040)  # TestLineBindingFail pipe_test.go:21-80
+    if which == "source":
+        line.src_err_on_make = True
+    elif which == "processor":
+        line.procs[0].err_on_make = True
+    else:
+        line.sink_err_on_make = True
+    err, _ = H.run(BUF, [line], H.MODE_ASYNC)
+    assert err.failed and err.is_mock_error and err.is_bind_error and err.message.startswith(which)
+
+
+def test_host_loop_equals_oracle_loop_on_counts_and_values():
+    # product loop (C++) and oracle loop (C) on the same synthetic 2-channel stream
+    frames = 7 * BUF + 77
+    hl = H.Line(limit=frames, channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(1),
+                procs=[H.Proc(H.PROC_MOCK), H.Proc(H.PROC_MOCK)], discard=False)
+    ol = O.Line(limit=frames, channels=2, src_kind=O.SRC_SYNTH, seed=synth.line_seed(1),
+                procs=[O.Proc(O.PROC_COPY), O.Proc(O.PROC_COPY)], discard=False)
+    herr, hres = H.run(BUF, [hl])
+    oerr, ores = O.run_lines(BUF, [ol])
+    assert not herr.failed and oerr.ok
+    assert np.array_equal(hres[0].values, ores[0].values)
+    assert (hres[0].sink.messages, hres[0].sink.samples) == (ores[0].sink.messages, ores[0].sink.samples)
+
+
+# ------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_hip_copy_in_the_loop_config1(mode):
+    # BASELINE configs[0]: mock.Source -> Processor(gain 1.0) -> mock.Sink, 512-frame buffers
+    err, res = H.run(BUF, [H.Line(limit=862 * BUF, channels=2, value=1.0, discard=True,
+                                   procs=[H.Proc(H.PROC_HIP_COPY)])], mode)
+    assert not err.failed, err.message
+    assert_line(res[0], 862, 862 * BUF)
+    err, res = H.run(BUF, [H.Line(limit=1040, channels=2, value=2.0, discard=False,
+                                   procs=[H.Proc(H.PROC_HIP_COPY)])], mode)
+    assert not err.failed
+    assert_line(res[0], 3, 1040)
+    assert res[0].values.size == 2080 and np.all(res[0].values == 2.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_hip_fir_biquad_gain_lines_equal_oracle_loop(mode):
+    C_, frames = 2, 9 * BUF + 200
+    taps = synth.fir_lowpass_taps(256)
+    sos = synth.biquad_rbj_lowpass()
+    hlines, olines = [], []
+    for i in range(3):  # three Lines round-robin / concurrently, different lengths
+        n = frames - i * 300
+        hlines.append(H.Line(limit=n, channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                             procs=[H.Proc(H.PROC_HIP_FIR, taps), H.Proc(H.PROC_HIP_BIQUAD, sos),
+                                    H.Proc(H.PROC_HIP_GAIN, [0.5])]))
+        olines.append(O.Line(limit=n, channels=C_, src_kind=O.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                             procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_BIQUAD, sos), O.Proc(O.PROC_GAIN, [0.5])]))
+    herr, hres = H.run(BUF, hlines, mode)
+    oerr, ores = O.run_lines(BUF, olines)
+    assert not herr.failed, herr.message
+    for h, o in zip(hres, ores):
+        assert (h.sink.messages, h.sink.samples) == (o.sink.messages, o.sink.samples)
+        assert np.array_equal(h.values, o.values)  # float64 buffers: bit-exact
+
+
+@pytest.mark.gpu
+def test_hip_fused_chain_equals_separate_stages_and_oracle():
+    C_, frames = 8, 3 * BUF + 5
+    taps = synth.fir_lowpass_taps(64)
+    sos = synth.biquad_rbj_lowpass()
+    src = dict(limit=frames, channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(4), discard=False)
+    fused = H.Line(procs=[H.Proc(H.PROC_HIP_CHAIN, H.chain_params(taps, sos, 0.25))], **src)
+    herr, hres = H.run(BUF, [fused])
+    ol = O.Line(limit=frames, channels=C_, src_kind=O.SRC_SYNTH, seed=synth.line_seed(4), discard=False,
+                procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_BIQUAD, sos), O.Proc(O.PROC_GAIN, [0.25])])
+    oerr, ores = O.run_lines(BUF, [ol])
+    assert not herr.failed, herr.message
+    assert np.array_equal(hres[0].values, ores[0].values)
+
+
+@pytest.mark.gpu
+def test_mutation_reaches_hip_handle_through_the_message():
+    # an initializer mutation (pipe.go:205-206) rides the first Message down the Line
+    # and is applied in the processing thread before ProcessFunc (pipe.go:433)
+    line = H.Line(limit=1040, channels=2, value=1.0, discard=False,
+                  procs=[H.Proc(H.PROC_HIP_GAIN, [1.0], mutate_gain=0.25)])
+    err, res = H.run(BUF, [line], H.MODE_ASYNC)
+    assert not err.failed, err.message
+    assert np.all(res[0].values == 0.25)
+
+
+@pytest.mark.gpu
+def test_hip_processor_error_surfaces_as_run_error():
+    line = H.Line(limit=1040, channels=1, procs=[H.Proc(H.PROC_HIP_GAIN, [1.0], err_on_call=True)])
+    err, res = H.run(BUF, [line])
+    assert err.failed and err.is_mock_error
+    assert res[0].source.flushed and res[0].procs[0].flushed and res[0].sink.flushed
