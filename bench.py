@@ -59,24 +59,17 @@ def main():
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from pipe_amd import processors as P
+    from pipe_amd import shard, synth
+
+    rank, world, local = shard.rank_from_env()
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-
-    from pipe_amd import processors as P
-    from pipe_amd import synth
+    # RCCL only for the barrier and the max-over-ranks: Lines do not communicate
+    dist = shard.init("nccl", rank, world, device=torch.device("cuda", local))
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -88,19 +81,18 @@ def main():
     fir = P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=L, max_batch=K)
     fir.start()
 
-    # synthetic input, generated on the device: Line index = rank*L + l
+    # synthetic input, generated on the device; global Line i lives on rank i mod world
+    my_lines = shard.line_indices(rank, world, L * world)
     d_in = torch.empty(n_elems, dtype=t_dtype, device="cuda")
     d_out = torch.empty_like(d_in)
-    for l in range(L):
-        P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C],
-                     synth.line_seed(rank * L + l))
+    for l, gl in enumerate(my_lines):
+        P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl))
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        shard.barrier(dist)
 
     for _ in range(args.warmup):
         fir.process_batch(d_in, d_out, frames_per_line, stream=stream)
@@ -121,10 +113,7 @@ def main():
     fir.set_profiling(False)
     kname = fir.kernel_name()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
 
     # a cheap self-check that work really happened: DC gain of the filter is 1, so
     # the output mean tracks the input mean (no oracle here: that is tests/ + smoke())
@@ -132,8 +121,7 @@ def main():
     chk_out = float(d_out[N * C: (1 << 20)].double().mean().item())
 
     samples_per_step_rank = n_elems                 # scalar samples = frames x channels
-    total_samples = samples_per_step_rank * world * args.steps
-    value = total_samples / elapsed / 1e6
+    value = shard.aggregate_throughput(samples_per_step_rank, args.steps, world, elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     bps = BYTES_PER_SAMPLE[args.dtype]
     avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3

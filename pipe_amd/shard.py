@@ -1,0 +1,64 @@
+"""Line -> rank sharding and cross-rank timing for multi-GPU runs.
+
+Lines are independent units of work (run.go:112-132 iterates them round-robin, no
+state is shared between them), so N GPUs = N processes, each owning a static
+slice of the Lines; there is no data-path collective.  The only communication is
+the barrier that brackets the timed region and a MAX all-reduce of the elapsed
+time, which works identically over RCCL ("nccl") on GPUs and gloo on CPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+
+def line_indices(rank: int, world: int, total_lines: int) -> List[int]:
+    """Static round-robin: Line i runs on rank i mod world."""
+    return list(range(rank, total_lines, world))
+
+
+def rank_from_env() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str, rank: int, world: int, device=None):
+    """Returns torch.distributed (initialised) or None for a single process."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kw = {}
+    if device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def barrier(dist) -> None:
+    if dist is not None:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, dist, device: Optional[str] = None) -> float:
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, dist, device: Optional[str] = None) -> float:
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def aggregate_throughput(samples_per_rank_step: int, steps: int, world: int, max_elapsed_s: float) -> float:
+    """Whole-job Msamples/s: all ranks' samples over the slowest rank's time."""
+    return samples_per_rank_step * world * steps / max_elapsed_s / 1e6

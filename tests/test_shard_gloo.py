@@ -1,0 +1,67 @@
+"""world_size-2 CPU test (gloo) of the N>1 path of bench.py: Line sharding, the
+barrier-bracketed timed region and the max-over-ranks reduction (pipe_amd/shard.py).
+The per-rank work is a stand-in: the oracle FIR over the rank's own Lines, which
+also proves that sharded Lines reproduce the single-process result exactly."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_lines, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from oracle import oracle as O
+    from pipe_amd import shard, synth
+    dist = shard.init("gloo", rank, world)
+    mine = shard.line_indices(rank, world, total_lines)
+    taps = synth.fir_lowpass_taps(32)
+    shard.barrier(dist)
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))  # rank 1 is the slow one
+    sums = {}
+    for l in mine:
+        x = synth.samples(synth.line_seed(l), 0, 2 * 512).reshape(512, 2)
+        sums[l] = float(O.Fir(taps, 2).process(x).sum())
+    shard.barrier(dist)
+    elapsed = time.perf_counter() - t0
+    worst = shard.max_over_ranks(elapsed, dist)
+    n_lines = shard.sum_over_ranks(float(len(mine)), dist)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"),
+            np.array([elapsed, worst, n_lines] + [v for _, v in sorted(sums.items())] ))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_timing(tmp_path):
+    world, total_lines = 2, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total_lines, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "r0.npy")
+    r1 = np.load(tmp_path / "r1.npy")
+    # both ranks agree on the max, and it is at least the slow rank's sleep
+    assert r0[1] == r1[1] and r0[1] >= max(r0[0], r1[0]) - 1e-9 and r0[1] >= 0.1
+    assert r0[2] == total_lines and r1[2] == total_lines
+    # every Line processed exactly once, with the single-process result
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from pipe_amd import shard, synth
+    assert sorted(shard.line_indices(0, 2, 5) + shard.line_indices(1, 2, 5)) == list(range(5))
+    taps = synth.fir_lowpass_taps(32)
+    want = {l: float(O.Fir(taps, 2).process(synth.samples(synth.line_seed(l), 0, 1024).reshape(512, 2)).sum())
+            for l in range(total_lines)}
+    got = dict(zip(shard.line_indices(0, 2, 5), r0[3:]))
+    got.update(zip(shard.line_indices(1, 2, 5), r1[3:]))
+    assert got == want
+    assert shard.aggregate_throughput(1000, 10, 2, 0.5) == 1000 * 2 * 10 / 0.5 / 1e6
