@@ -5,18 +5,26 @@
 //     acc = +0.0;  for k = 0..N-1:  acc = fma(h[k], x[n-k], acc)      (binary64)
 //
 // Mapping to CDNA4:
-//   * one workgroup = one (Line, frame tile, channel group); the tile's input
-//     window (tile + history) is staged ONCE from HBM into LDS, de-interleaved
-//     into per-channel planes and widened to f64, with one pad element every R
-//     elements so that the lanes of a wave (stride R) fall on distinct LDS banks;
+//   * a tile = (Line, TF frames, channel group).  Workgroups (256 lanes, one wave
+//     per SIMD, two workgroups per CU) are PERSISTENT: each walks tiles id,
+//     id+grid, ...  While tile t is being computed, the global loads of tile
+//     t+grid are already in flight into registers (issue-early / write-late), so
+//     HBM/L2 latency hides under the tap loop instead of in front of it.
+//   * the tile's input window (tile + history) sits in LDS, de-interleaved into
+//     per-channel planes and widened to f64, one pad element every R elements and
+//     a plane stride chosen so that the lanes of each 32-lane group fall on
+//     distinct banks for ds_read_b64;
 //   * one lane = R consecutive frames of one channel: R independent f64
-//     accumulators, a 2R-deep register window that slides one frame per tap, so
-//     each tap costs one ds_read_b64 per R v_fma_f64;
-//   * taps are wave-uniform: they are read through the scalar cache (s_load) and
-//     enter v_fma_f64 as an SGPR operand -- no VGPR / LDS traffic for taps;
-//   * results go back through LDS so the global store is fully coalesced.
+//     accumulators and a 2R-deep register window that slides one frame per tap,
+//     so each tap costs one ds_read_b64 per R v_fmac_f64;
+//   * taps are wave-uniform: read through the constant address space
+//     (s_load_dwordx16) they enter v_fmac_f64 as its SGPR operand -- no VGPR or
+//     LDS traffic for coefficients;
+//   * a wave owns a contiguous span of output frames for all channels of the
+//     group, so results are transposed through a wave-private LDS slab (no
+//     workgroup barrier) and leave as fully coalesced stores.
 // The kernel is bound by the f64 VALU rate (2*N flop per scalar sample against
-// 8 B of HBM traffic): DESIGN.md "Roofline".
+// 8 B of HBM traffic): DESIGN.md "Kernels and their rooflines".
 #include <cstdlib>
 
 #include "common.hpp"
@@ -25,22 +33,35 @@ namespace pipehip {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTaps = 4096;
 constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kPF = 24;  // prefetch registers per lane (rows of the next tile)
+#ifndef PIPE_HIP_FIR_LDS_TAPS
+#define PIPE_HIP_FIR_LDS_TAPS 0
+#endif
+constexpr bool kLdsTaps = PIPE_HIP_FIR_LDS_TAPS != 0;
 
 struct FirArgs {
-    int64_t frames;      // frames per Line in this call
-    int64_t line_stride; // elements between consecutive Lines (= frames*C)
-    int C;               // channels
-    int CG;              // channels per workgroup
-    int N, H;            // taps, history frames (N-1)
-    int HP;              // staged history frames, multiple of R, >= H
-    int FB;              // frame blocks (lanes) per channel per tile
-    int TF;              // frames per tile = FB*R
-    int plane;           // padded plane length (elements)
-    int nfull, rem;      // N = nfull*R + rem
-    int cx_log;          // log2 of the staging column count (2^cx_log >= CG)
-    int ablate;          // tuning only (PIPE_HIP_FIR_ABLATE): 1 = skip staging loads, 2 = skip taps
+    int64_t frames;       // frames per Line in this call
+    int64_t line_stride;  // elements between consecutive Lines (= frames*C)
+    int C;                // channels
+    int CG;               // channels per tile
+    int lines;
+    int tiles_per_line;
+    int ntiles;           // tiles_per_line * lines * channel groups
+    int N, H;             // taps, history frames (N-1)
+    int HP;               // staged history frames: multiple of R, >= H
+    int lpc_log;          // log2(LPC), LPC = lanes per channel within a wave
+    int cx_log;           // log2(CX), CX = pow2 >= CG = staging columns
+    int TF;               // frames per tile = kWaves * LPC * R
+    int plane;            // plane stride in elements (bank-spread)
+    int rows;             // staging rows per lane = ceil((TF+HP) / (256/CX))
+    int prefetch;         // rows <= kPF: next tile's loads are issued before compute
+    int nfull, rem;       // N = nfull*R + rem
+    int out_off;          // byte offset of the wave-private output slabs in LDS
+    int out_slab;         // elements per slab (padded)
+    int taps_off;         // byte offset of the LDS copy of the taps
 };
 
 // Taps are wave-uniform and immutable during a launch: reading them through the
@@ -59,9 +80,9 @@ __device__ __forceinline__ int pad_index(int f)
 // All register indices are compile-time constants; a TAIL block guards each tap
 // with a wave-uniform (scalar) branch instead of padding with zero taps, so NaN /
 // Inf handling stays identical to the oracle.
-template <int R, bool TAIL>
+template <int R, bool TAIL, typename TapPtr>
 __device__ __forceinline__ void fir_tap_block(double (&acc)[R], const double (&cur)[R],
-                                              const double (&nxt)[R], const_f64_ptr taps, int rem)
+                                              const double (&nxt)[R], TapPtr taps, int rem)
 {
 #pragma unroll
     for (int kk = 0; kk < R; ++kk) {
@@ -76,6 +97,24 @@ __device__ __forceinline__ void fir_tap_block(double (&acc)[R], const double (&c
     }
 }
 
+struct TileCoord {
+    int line, c0, cg;
+    int64_t t0;
+};
+
+__device__ __forceinline__ TileCoord decode_tile(const FirArgs &a, int id)
+{
+    TileCoord t;
+    const int tile = id % a.tiles_per_line;
+    const int rest = id / a.tiles_per_line;
+    t.line = rest % a.lines;
+    const int g = rest / a.lines;
+    t.c0 = g * a.CG;
+    t.cg = min(a.CG, a.C - t.c0);
+    t.t0 = (int64_t)tile * a.TF;
+    return t;
+}
+
 template <int R, typename TIn, typename TOut>
 __global__ void __launch_bounds__(kThreads)
 fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
@@ -84,88 +123,139 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *xs = reinterpret_cast<double *>(smem_raw);
+    constexpr int kStep = R > 1 ? R + 1 : 1;
 
-    const int line = blockIdx.y;
-    const int c0 = blockIdx.z * a.CG;
-    const int cg = min(a.CG, a.C - c0);
-    const int64_t t0 = (int64_t)blockIdx.x * a.TF;
-    const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-    const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
-
-    // ---- stage [t0-HP, t0+TF) x cg channels into per-channel planes --------
-    // lane -> (channel tx, frame row ty) by shifts (CX = 2^cx_log >= cg); kUnroll
-    // independent loads are issued before the first is consumed, so a wave keeps
-    // kUnroll HBM/L2 requests in flight instead of one.
-    const int cx_log = a.cx_log;
-    const int tx = threadIdx.x & ((1 << cx_log) - 1);
-    const int ty = threadIdx.x >> cx_log;
-    const int FY = kThreads >> cx_log;
-    const bool tx_ok = tx < cg;
+    // staging map: lane -> (column tx = channel, row ty = frame) by shifts
+    const int tx = threadIdx.x & ((1 << a.cx_log) - 1);
+    const int ty = threadIdx.x >> a.cx_log;
+    const int FY = kThreads >> a.cx_log;
     const int nfr = a.TF + a.HP;
-    // frames f < nh precede this call: history (or zeros before it)
-    const int64_t nh64 = (int64_t)a.HP - t0;
-    const int nh = nh64 > 0 ? (int)nh64 : 0;
-    for (int f = ty; f < nh; f += FY) {
-        const int64_t g = t0 - a.HP + f;  // < 0
-        double v = 0.0;
-        if (tx_ok && g >= -(int64_t)a.H)
-            v = hist[(g + a.H) * a.C + c0 + tx];
-        if (tx_ok)
-            xs[tx * a.plane + pad_index<R>(f)] = v;
+    const int64_t last = a.frames - 1;
+
+    // compute map: wave w, lane l -> channel cl = l / LPC, frame block w*LPC + l % LPC
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int cl = lane >> a.lpc_log;
+    const int fbl = lane & ((1 << a.lpc_log) - 1);
+    const int LPC = 1 << a.lpc_log;
+    const int fb = wave * LPC + fbl;  // frame block within the tile
+    TOut *slab = reinterpret_cast<TOut *>(smem_raw + a.out_off) + (size_t)wave * a.out_slab;
+
+    // taps live in LDS for the whole (persistent) workgroup: inside the tap loop
+    // every load is then an in-order LDS read (broadcast for the tap), so the
+    // waits are counted instead of the full drain that SMEM loads would force
+    const double *ltaps = reinterpret_cast<const double *>(smem_raw + a.taps_off);
+    if constexpr (kLdsTaps) {
+        double *lt = reinterpret_cast<double *>(smem_raw + a.taps_off);
+        for (int k = threadIdx.x; k < a.N; k += kThreads)
+            lt[k] = taps_base[k];
     }
-    {
-        constexpr int kUnroll = 8;
-        const int64_t last = a.frames - 1;
-        // lanes beyond the channel group read channel 0 and discard it: keeps the
-        // loads unconditional so that they can all be issued before the first wait
-        const TIn *__restrict__ src = in + c0 + (tx_ok ? tx : 0);
-        // first row >= nh that this lane owns
-        int f0 = ty;
-        if (f0 < nh)
-            f0 += ((nh - f0 + FY - 1) / FY) * FY;
-        for (int fb = f0; fb < nfr && !(a.ablate & 1); fb += kUnroll * FY) {
-            TIn v[kUnroll];
+
+    TIn pf[kPF];
+    int id = blockIdx.x;
+    TileCoord tc = decode_tile(a, id < a.ntiles ? id : 0);
+
+    // Interior tiles (no history, no end of stream inside the staged rows) are
+    // addressed linearly: one base pointer per lane plus u*FY*C, no clamps, so the
+    // prefetch costs kPF registers and little else.  Boundary tiles take
+    // stage_sync() below when their turn comes.
+    auto interior = [&](const TileCoord &t) -> bool {
+        const int64_t first = t.t0 - a.HP;
+        return a.prefetch && first >= 0 && first + (int64_t)a.rows * FY - 1 <= last;
+    };
+    auto issue = [&](const TileCoord &t) {
+        const TIn *__restrict__ src = in_base + (int64_t)t.line * a.line_stride +
+                                      (t.t0 - a.HP + ty) * a.C + t.c0 + (tx < t.cg ? tx : 0);
+        const int64_t stride = (int64_t)FY * a.C;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                int64_t g = t0 - a.HP + fb + u * FY;
-                g = g > last ? last : g;  // clamped: the value is discarded below
+        for (int u = 0; u < kPF; ++u)
+            if (u < a.rows)
+                pf[u] = src[u * stride];
+    };
+    // write pf[] into the planes
+    auto commit = [&](const TileCoord &t) {
+        if (tx < t.cg) {
+            double *__restrict__ dst = xs + tx * a.plane;
+#pragma unroll
+            for (int u = 0; u < kPF; ++u) {
+                const int f = ty + u * FY;
+                if (u < a.rows && f < nfr)
+                    dst[pad_index<R>(f)] = (double)pf[u];
+            }
+        }
+    };
+    // boundary tiles, and windows too long to prefetch in registers: clamped
+    // loads, written in place
+    auto stage_sync = [&](const TileCoord &t) {
+        const bool ok = tx < t.cg;
+        const TIn *__restrict__ src =
+            in_base + (int64_t)t.line * a.line_stride + t.c0 + (ok ? tx : 0);
+        const double *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
+        for (int fb0 = ty; fb0 < nfr; fb0 += 8 * FY) {
+            TIn v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int64_t g = t.t0 - a.HP + fb0 + u * FY;
+                g = g < 0 ? 0 : (g > last ? last : g);
                 v[u] = src[g * a.C];
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int f = fb + u * FY;
-                const int64_t g = t0 - a.HP + f;
-                if (tx_ok && f < nfr)
-                    xs[tx * a.plane + pad_index<R>(f)] = g <= last ? (double)v[u] : 0.0;
+            for (int u = 0; u < 8; ++u) {
+                const int f = fb0 + u * FY;
+                const int64_t g = t.t0 - a.HP + f;
+                const double loaded = (double)v[u];  // unconditional use: no load stays pending
+                if (ok && f < nfr) {
+                    double w = 0.0;
+                    if (g >= 0)
+                        w = g <= last ? loaded : 0.0;
+                    else if (g >= -(int64_t)a.H)
+                        w = hist[(g + a.H) * a.C + t.c0 + tx];
+                    xs[tx * a.plane + pad_index<R>(f)] = w;
+                }
             }
         }
-    }
-    __syncthreads();
+    };
 
-    // ---- compute ---------------------------------------------------------------
-    const int items = a.FB * cg;
-    const int passes = (items + kThreads - 1) / kThreads;
-    TOut *os = reinterpret_cast<TOut *>(smem_raw);
-    TOut *__restrict__ out = out_base + (int64_t)line * a.line_stride;
-    constexpr int kStep = R > 1 ? R + 1 : 1;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int item = pass * kThreads + threadIdx.x;
-        const bool active = item < items;
+    bool fast = id < a.ntiles && interior(tc);
+    if (fast)
+        issue(tc);
+
+    while (id < a.ntiles) {
+        if (fast)
+            commit(tc);
+        else
+            stage_sync(tc);
+        __syncthreads();  // planes of tile `id` are complete
+
+        const TileCoord cur_t = tc;
+        const int next = id + gridDim.x;
+        fast = false;
+        if (next < a.ntiles) {
+            tc = decode_tile(a, next);
+            fast = interior(tc);
+            if (fast)
+                issue(tc);  // in flight during the tap loop below
+        }
+
+        // ---- tap loop ---------------------------------------------------------
         double acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = 0.0;
-        int cl = 0, fb = 0;
+        const bool active = cl < cur_t.cg;
         if (active) {
-            cl = item / a.FB;
-            fb = item - cl * a.FB;
             // group g of a plane holds frames [g*R, g*R+R) at elements g*(R+1)..+R-1
             const double *w = xs + cl * a.plane + (fb + a.HP / R) * kStep;
             double cur[R], nxt[R];
 #pragma unroll
             for (int j = 0; j < R; ++j)
                 cur[j] = w[j];
-            const_f64_ptr tp = (const_f64_ptr)taps_base;
+            auto tp = [&] {
+                if constexpr (kLdsTaps)
+                    return ltaps;
+                else
+                    return (const_f64_ptr)taps_base;
+            }();
             // two tap blocks per trip so the window registers swap roles
             // instead of being copied
             int kb = 0;
@@ -201,33 +291,43 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 fir_tap_block<R, true>(acc, cur, nxt, tp, a.rem);
             }
         }
-        // ---- results through LDS for a coalesced store -------------------------
-        // (single pass is the common case; with several passes the planes are
-        // still needed, so store straight from registers instead)
-        if (passes == 1) {
-            __syncthreads();  // every lane is done reading the planes
-            if (active) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int o = (fb * R + r) * cg + cl;
-                    os[o + (o >> 5)] = (TOut)acc[r];
-                }
-            }
-            __syncthreads();
-            for (int f = ty; f < a.TF; f += FY) {
-                const int64_t g = t0 + f;
-                const int i = f * cg + tx;
-                if (tx_ok && g < a.frames)
-                    out[g * a.C + c0 + tx] = os[i + (i >> 5)];
-            }
-        } else if (active) {
+
+        // ---- wave-private transpose + coalesced store -------------------------
+        // the wave owns frames [t0 + wave*LPC*R, +LPC*R) for every channel of the
+        // group: slab element (frame offset, channel) -> o = foff*cg + c
+        const int cg = cur_t.cg;
+        if (active) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int64_t g = t0 + (int64_t)fb * R + r;
-                if (g < a.frames)
-                    out[g * a.C + c0 + cl] = (TOut)acc[r];
+                const int o = (fbl * R + r) * cg + cl;
+                slab[o + (o >> 5)] = (TOut)acc[r];
             }
         }
+        // same-wave LDS ordering only: no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int64_t f0 = cur_t.t0 + (int64_t)wave * LPC * R;  // first frame of the wave
+            TOut *__restrict__ out = out_base + (int64_t)cur_t.line * a.line_stride;
+            const int nel = LPC * R * cg;
+            int64_t lim = (a.frames - f0) * cg;  // elements that fall inside the call
+            if (lim > nel)
+                lim = nel;
+            if (cg == a.C) {
+                TOut *__restrict__ dst = out + f0 * a.C;
+                for (int e = lane; e < lim; e += 64)
+                    dst[e] = slab[e + (e >> 5)];
+            } else {
+                for (int e = lane; e < lim; e += 64) {
+                    const int f = e / cg;
+                    const int c = e - f * cg;
+                    out[(f0 + f) * a.C + cur_t.c0 + c] = slab[e + (e >> 5)];
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the planes before they are rewritten
+        id = next;
     }
 }
 
@@ -253,10 +353,45 @@ __global__ void fir_hist_update_kernel(const TIn *__restrict__ in, const double 
 }
 
 struct Geometry {
-    int R, CG, FB, TF, HP, plane;
-    size_t lds;
-    int64_t blocks;
+    int R, CG, ngroups, cgp, lpc_log, cx_log, TF, HP, plane, rows, prefetch, out_slab;
+    size_t out_off, taps_off, lds;
+    int64_t tiles_per_line, ntiles;
 };
+
+int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v)
+        ++l;
+    return l;
+}
+
+// smallest plane stride >= minlen whose residue spreads the (channel, frame
+// block) lanes of each 32-lane ds_read_b64 group over distinct 8-byte slots
+int pick_plane_stride(int minlen, int R, int lpc_log)
+{
+    const int step = R > 1 ? R + 1 : 1;
+    const int LPC = 1 << lpc_log;
+    for (int extra = 0; extra < 64; ++extra) {
+        const int ps = minlen + extra;
+        bool ok = true;
+        for (int half = 0; half < 2 && ok; ++half) {
+            unsigned seen = 0;
+            for (int l = half * 32; l < half * 32 + 32; ++l) {
+                const int cl = l >> lpc_log, fbl = l & (LPC - 1);
+                const int slot = (int)(((int64_t)cl * ps + (int64_t)fbl * step) & 31);
+                if (seen & (1u << slot)) {
+                    ok = false;
+                    break;
+                }
+                seen |= 1u << slot;
+            }
+        }
+        if (ok)
+            return ps;
+    }
+    return minlen;
+}
 
 class Fir final : public pipe_hip_processor {
 public:
@@ -271,10 +406,12 @@ public:
         PH_TRY(hist_[0].alloc(hb));
         PH_TRY(hist_[1].alloc(hb));
         hist_bytes_ = hb;
-        // the largest tile geometry must fit in LDS for at least R = 1
+        hipDeviceProp_t prop;
+        PH_HIP(hipGetDeviceProperties(&prop, cfg.device));
+        cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         Geometry g;
-        if (!geometry(1, 1, &g))
-            return PIPE_HIP_EINVAL;
+        if (!choose(1, &g))
+            return PIPE_HIP_EINVAL;  // window does not fit in LDS even at R = 1
         return start(stream);
     }
 
@@ -312,28 +449,25 @@ public:
         a.line_stride = frames * cfg.channels;
         a.C = cfg.channels;
         a.CG = g.CG;
+        a.lines = cfg.lines;
+        a.tiles_per_line = (int)g.tiles_per_line;
+        a.ntiles = (int)g.ntiles;
         a.N = N_;
         a.H = H_;
         a.HP = g.HP;
-        a.FB = g.FB;
+        a.lpc_log = g.lpc_log;
+        a.cx_log = g.cx_log;
         a.TF = g.TF;
         a.plane = g.plane;
+        a.rows = g.rows;
+        a.prefetch = g.prefetch;
         a.nfull = N_ / g.R;
         a.rem = N_ % g.R;
-        a.cx_log = 0;
-        if (const char *ab = std::getenv("PIPE_HIP_FIR_ABLATE")) {
-            a.ablate = std::atoi(ab);
-            if (a.ablate & 2) {
-                a.nfull = 0;
-                a.rem = 0;
-            }
-        }
-        while ((1 << a.cx_log) < g.CG)
-            ++a.cx_log;
-        const dim3 grid((unsigned)((frames + g.TF - 1) / g.TF), (unsigned)cfg.lines,
-                        (unsigned)((cfg.channels + g.CG - 1) / g.CG));
+        a.out_off = (int)g.out_off;
+        a.out_slab = g.out_slab;
+        a.taps_off = (int)g.taps_off;
         PH_TRY(timer.begin(s));
-        PH_TRY(launch(g, in_dtype, out_dtype, grid, d_in, d_out, hist, taps, a, s));
+        PH_TRY(launch(g, in_dtype, out_dtype, d_in, d_out, hist, taps, a, s));
         PH_TRY(timer.end(s));
         if (H_ > 0) {
             const int n = H_ * cfg.channels;
@@ -354,32 +488,40 @@ public:
     }
 
 private:
-    // tile geometry for register blocking R and a channel-group divisor
-    bool geometry(int R, int split, Geometry *g) const
+    // tile geometry for register blocking R with the channels split `split` ways
+    bool geometry(int R, int split, int64_t frames, Geometry *g) const
     {
         const int C = cfg.channels;
-        int CG = (C + split - 1) / split;
-        int FB = (kThreads / CG) / 32 * 32;
-        if (FB < 32)
-            FB = 32;
+        const int CG = (C + split - 1) / split;
         g->R = R;
         g->CG = CG;
-        g->FB = FB;
-        g->TF = FB * R;
+        g->ngroups = (C + CG - 1) / CG;
+        g->cx_log = ilog2(CG);
+        g->cgp = 1 << g->cx_log;  // <= 64 because channels <= 64
+        g->lpc_log = 6 - g->cx_log;
+        const int LPC = 1 << g->lpc_log;
+        g->TF = kWaves * LPC * R;
         g->HP = ((N_ + R - 1) / R) * R;
         const int groups = (g->TF + g->HP) / R;
-        g->plane = R > 1 ? groups * (R + 1) : groups;
-        size_t in_bytes = sizeof(double) * (size_t)g->plane * (size_t)CG;
-        size_t out_elems = (size_t)g->TF * (size_t)CG;
-        size_t out_bytes = sizeof(double) * (out_elems + (out_elems >> 5) + 1);
-        g->lds = in_bytes > out_bytes ? in_bytes : out_bytes;
-        return g->lds <= kMaxLds;
+        g->plane = pick_plane_stride(R > 1 ? groups * (R + 1) : groups, R, g->lpc_log);
+        const int FY = kThreads >> g->cx_log;
+        g->rows = (g->TF + g->HP + FY - 1) / FY;
+        g->prefetch = g->rows <= kPF ? 1 : 0;
+        const size_t in_bytes = sizeof(double) * (size_t)g->plane * (size_t)g->cgp;
+        const int slab_el = LPC * R * CG;
+        g->out_slab = slab_el + (slab_el >> 5) + 2;
+        g->out_off = (in_bytes + 15) & ~(size_t)15;
+        g->taps_off = g->out_off + sizeof(double) * (size_t)g->out_slab * kWaves;
+        g->lds = g->taps_off + sizeof(double) * (size_t)N_;
+        g->tiles_per_line = (frames + g->TF - 1) / g->TF;
+        g->ntiles = g->tiles_per_line * cfg.lines * g->ngroups;
+        return g->lds <= kMaxLds && g->ntiles < (int64_t)1 << 30;
     }
 
     // Largest register blocking R that still gives the chip >= 2 workgroups per
     // CU; small calls fall back to smaller R (more, shorter lanes).  A tile that
-    // would not leave room for 2 workgroups per CU in LDS is split across
-    // channel groups.
+    // would not leave LDS room for 2 workgroups per CU is split across channel
+    // groups.
     bool choose(int64_t frames, Geometry *best) const
     {
         static const int Rs[] = {16, 8, 4, 2, 1};
@@ -387,29 +529,29 @@ private:
         // tuning knob for experiments: PIPE_HIP_FIR_R pins the register blocking
         const char *force = std::getenv("PIPE_HIP_FIR_R");
         const int forced = force ? std::atoi(force) : 0;
+        const int64_t want = 2 * (int64_t)cus_;
         for (int R : Rs) {
             if (forced && R != forced)
                 continue;
             Geometry g;
             int split = 1;
-            bool ok = geometry(R, split, &g);
-            while ((!ok || g.lds > 64 * 1024) && split < cfg.channels)
-                ok = geometry(R, ++split, &g);
+            bool ok = geometry(R, split, frames, &g);
+            while ((!ok || g.lds > 80 * 1024) && split < cfg.channels)
+                ok = geometry(R, ++split, frames, &g);
             if (!ok)
                 continue;
-            g.blocks = ((frames + g.TF - 1) / g.TF) * cfg.lines * ((cfg.channels + g.CG - 1) / g.CG);
-            if (!have || g.blocks > best->blocks)
+            if (!have || g.ntiles > best->ntiles)
                 *best = g;
             have = true;
-            if (g.blocks >= 512)
+            if (g.ntiles >= want)
                 break;
         }
         return have;
     }
 
     template <int R>
-    int launch_r(int in_dtype, int out_dtype, const Geometry &g, dim3 grid, const void *d_in,
-                 void *d_out, const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
+    int launch_r(int in_dtype, int out_dtype, const Geometry &g, const void *d_in, void *d_out,
+                 const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
 #define PH_FIR_LAUNCH(TI, TO, NAME)                                                                  \
     do {                                                                                             \
@@ -417,6 +559,7 @@ private:
         if (g.lds > 64 * 1024)                                                                       \
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
+        const dim3 grid = persistent_grid(reinterpret_cast<const void *>(kfn), g);                   \
         hipLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, static_cast<const TI *>(d_in),      \
                            static_cast<TO *>(d_out), hist, taps, a);                                 \
         last_kernel = NAME;                                                                          \
@@ -434,19 +577,38 @@ private:
         return PIPE_HIP_OK;
     }
 
-    int launch(const Geometry &g, int in_dtype, int out_dtype, dim3 grid, const void *d_in,
-               void *d_out, const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
+    // Persistent grid: as many workgroups as the CUs can hold at once (VGPR / LDS
+    // occupancy of this kernel variant), tiles dealt round-robin and balanced so
+    // that every workgroup walks the same number of tiles.
+    dim3 persistent_grid(const void *kfn, const Geometry &g)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kThreads, g.lds) != hipSuccess ||
+            per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 2;
+        }
+        if (const char *f = std::getenv("PIPE_HIP_FIR_WGS_PER_CU"))  // tuning knob
+            per_cu = std::atoi(f) > 0 ? std::atoi(f) : per_cu;
+        const int64_t slots = (int64_t)per_cu * cus_;
+        const int64_t per = (g.ntiles + slots - 1) / slots;
+        return dim3((unsigned)((g.ntiles + per - 1) / per));
+    }
+
+    int launch(const Geometry &g, int in_dtype, int out_dtype, const void *d_in, void *d_out,
+               const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
         switch (g.R) {
-        case 16: return launch_r<16>(in_dtype, out_dtype, g, grid, d_in, d_out, hist, taps, a, s);
-        case 8: return launch_r<8>(in_dtype, out_dtype, g, grid, d_in, d_out, hist, taps, a, s);
-        case 4: return launch_r<4>(in_dtype, out_dtype, g, grid, d_in, d_out, hist, taps, a, s);
-        case 2: return launch_r<2>(in_dtype, out_dtype, g, grid, d_in, d_out, hist, taps, a, s);
-        default: return launch_r<1>(in_dtype, out_dtype, g, grid, d_in, d_out, hist, taps, a, s);
+        case 16: return launch_r<16>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
+        case 8: return launch_r<8>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
+        case 4: return launch_r<4>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
+        case 2: return launch_r<2>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
+        default: return launch_r<1>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
         }
     }
 
     int N_ = 0, H_ = 0;
+    int cus_ = 256;
     DevBuf taps_[2];
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;
