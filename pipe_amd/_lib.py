@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpipe_hip.so")
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE = range(7)
 F32, F64 = 0, 1
-PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS = 0, 1, 2
+PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS, PARAM_EXACT = 0, 1, 2, 3
 
 
 class Config(C.Structure):

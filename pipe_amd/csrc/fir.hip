@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "fir_ols.hpp"
 
 namespace pipehip {
 namespace {
@@ -412,6 +413,10 @@ public:
         Geometry g;
         if (!choose(1, &g))
             return PIPE_HIP_EINVAL;  // window does not fit in LDS even at R = 1
+        if (ols::Plan::supports(N_, cfg.channels)) {
+            ols_.reset(new ols::Plan());
+            PH_TRY(ols_->init(cfg.device, taps, N_));
+        }
         return start(stream);
     }
 
@@ -424,6 +429,10 @@ public:
 
     int set_param(int32_t param, const double *values, int32_t count) override
     {
+        if (param == PIPE_HIP_PARAM_EXACT && count == 1 && values) {
+            exact_ = values[0] != 0.0;
+            return PIPE_HIP_OK;
+        }
         if (param != PIPE_HIP_PARAM_TAPS || count != N_ || !values)
             return PIPE_HIP_EINVAL;
         // double-buffered: launches already queued keep reading the old copy
@@ -431,6 +440,8 @@ public:
         const int nxt = cur_taps_ ^ 1;
         PH_HIP(hipMemcpy(taps_[nxt].p, values, sizeof(double) * (size_t)N_, hipMemcpyHostToDevice));
         cur_taps_ = nxt;
+        if (ols_)
+            PH_TRY(ols_->set_taps(values));
         return PIPE_HIP_OK;
     }
 
@@ -439,11 +450,22 @@ public:
     {
         if (frames <= 0)
             return PIPE_HIP_OK;
+        const double *hist = static_cast<const double *>(hist_[cur_hist_].p);
+        // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
+        // oracle); float64 output, small calls and exact mode keep the ordered-fma
+        // direct form (bit-exact).
+        if (ols_ && !exact_ && out_dtype == PIPE_HIP_F32 &&
+            ols_->items(frames, cfg.channels, cfg.lines) >= ols_min_items()) {
+            PH_TRY(timer.begin(s));
+            PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, frames, cfg.channels, cfg.lines, s,
+                             &last_kernel));
+            PH_TRY(timer.end(s));
+            return update_history(d_in, in_dtype, hist, frames, s);
+        }
         Geometry g;
         if (!choose(frames, &g))
             return PIPE_HIP_EINVAL;
         FirArgs a{};
-        const double *hist = static_cast<const double *>(hist_[cur_hist_].p);
         const double *taps = static_cast<const double *>(taps_[cur_taps_].p);
         a.frames = frames;
         a.line_stride = frames * cfg.channels;
@@ -469,25 +491,40 @@ public:
         PH_TRY(timer.begin(s));
         PH_TRY(launch(g, in_dtype, out_dtype, d_in, d_out, hist, taps, a, s));
         PH_TRY(timer.end(s));
+        return update_history(d_in, in_dtype, hist, frames, s);
+    }
+
+private:
+    // enough 1024-point transforms to give every SIMD of the chip a few
+    int64_t ols_min_items() const
+    {
+        if (const char *f = std::getenv("PIPE_HIP_FIR_OLS_MIN_ITEMS"))
+            return std::atoll(f);
+        return 8 * (int64_t)cus_;
+    }
+
+    // new history = last N-1 frames of (old history ++ this call's input)
+    int update_history(const void *d_in, int in_dtype, const double *hist, int64_t frames, hipStream_t s)
+    {
         if (H_ > 0) {
             const int n = H_ * cfg.channels;
             const dim3 hg((unsigned)((n + 255) / 256), (unsigned)cfg.lines);
             double *hn = static_cast<double *>(hist_[cur_hist_ ^ 1].p);
+            const int64_t line_stride = frames * cfg.channels;
             if (in_dtype == PIPE_HIP_F32)
                 hipLaunchKernelGGL(fir_hist_update_kernel<float>, hg, dim3(256), 0, s,
-                                   static_cast<const float *>(d_in), hist, hn, frames,
-                                   a.line_stride, H_, cfg.channels);
+                                   static_cast<const float *>(d_in), hist, hn, frames, line_stride, H_,
+                                   cfg.channels);
             else
                 hipLaunchKernelGGL(fir_hist_update_kernel<double>, hg, dim3(256), 0, s,
-                                   static_cast<const double *>(d_in), hist, hn, frames,
-                                   a.line_stride, H_, cfg.channels);
+                                   static_cast<const double *>(d_in), hist, hn, frames, line_stride, H_,
+                                   cfg.channels);
             PH_HIP(hipGetLastError());
             cur_hist_ ^= 1;
         }
         return PIPE_HIP_OK;
     }
 
-private:
     // tile geometry for register blocking R with the channels split `split` ways
     bool geometry(int R, int split, int64_t frames, Geometry *g) const
     {
@@ -613,6 +650,8 @@ private:
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;
     int cur_taps_ = 0, cur_hist_ = 0;
+    bool exact_ = std::getenv("PIPE_HIP_FIR_EXACT") != nullptr;
+    std::unique_ptr<ols::Plan> ols_;
 };
 
 }  // namespace

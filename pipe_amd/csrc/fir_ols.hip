@@ -1,0 +1,509 @@
+// Overlap-save FIR for gfx950: the O(log N) form of the FIR Processor.
+//
+// Why: the direct form costs 2*N f64 flop per scalar sample and is pinned at the
+// f64 VALU roof (~15 % of the HBM roofline at N = 256).  Overlap-save
+// with a 1024-point float64 FFT costs ~50 DP instructions per sample instead of
+// 256 and moves the kernel towards the memory roof.
+//
+// Numerics: everything is float64.  Two real channels ride one complex sequence
+// (z = ch0 + i*ch1; the taps are real, so Re/Im of the filtered sequence are the
+// two filtered channels).  The result differs from the oracle's ordered fma chain
+// by O(1e-16) absolute -- far below one float32 ulp -- so float32 output equals
+// the correctly rounded oracle value except where the float64 value sits within
+// ~1e-15 of a rounding boundary (then it is the neighbouring float32: 1 ulp).
+// The path is therefore used for float32 buffers only, never for float64 ones and
+// never when the handle asks for bit-exactness (PIPE_HIP_FIR_EXACT).
+//
+// Mapping: ONE WAVE = one 1024-point complex FFT, held as 16 complex values per
+// lane.  1024 = 16 x 16 x 4:
+//     A  : 16-point DFT in registers over n2           (n = n1 + 64*n2, lane = n1)
+//     B  : twiddle W1024^(n1*k2)                        (table in LDS)
+//     X1 : wave-private LDS exchange (conflict-free strides 66 / 1)
+//     C1 : 16-point DFT in registers over b             (n1 = a + 4*b)
+//     C2 : twiddle W64^(a*d)
+//     X2 : wave-private LDS exchange (strides 272 / 17 / 1)
+//     C3 : four 4-point DFTs in registers
+// then the spectrum is multiplied by the (pre-permuted, pre-scaled) tap spectrum
+// and the same steps run backwards with conjugate twiddles, ending in natural
+// order, lane n1 holding y[n1 + 64*n2].  No workgroup barrier is needed after
+// the tables are loaded; waves walk (Line, channel pair, tile) items on their own.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "common.hpp"
+#include "fir_ols.hpp"
+
+namespace pipehip {
+namespace ols {
+namespace {
+
+constexpr int kM = 1024;         // FFT size
+constexpr int kEx = 1088;        // doubles per wave-private exchange buffer
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+struct cd {
+    double re, im;
+};
+
+__device__ __forceinline__ cd cmul(cd a, cd b)
+{
+    cd r;
+    r.re = __builtin_fma(a.re, b.re, -(a.im * b.im));
+    r.im = __builtin_fma(a.re, b.im, a.im * b.re);
+    return r;
+}
+__device__ __forceinline__ cd cmulc(cd a, cd b)  // a * conj(b)
+{
+    cd r;
+    r.re = __builtin_fma(a.re, b.re, a.im * b.im);
+    r.im = __builtin_fma(a.im, b.re, -(a.re * b.im));
+    return r;
+}
+
+// 4-point DFT, SIGN = -1 forward (W4 = -i), +1 inverse (W4 = +i)
+template <int SIGN>
+__device__ __forceinline__ void dft4(cd &x0, cd &x1, cd &x2, cd &x3)
+{
+    const cd s02{x0.re + x2.re, x0.im + x2.im};
+    const cd d02{x0.re - x2.re, x0.im - x2.im};
+    const cd s13{x1.re + x3.re, x1.im + x3.im};
+    const cd d13{x1.re - x3.re, x1.im - x3.im};
+    // SIGN * i * d13
+    const cd j13 = SIGN < 0 ? cd{d13.im, -d13.re} : cd{-d13.im, d13.re};
+    x0 = cd{s02.re + s13.re, s02.im + s13.im};
+    x2 = cd{s02.re - s13.re, s02.im - s13.im};
+    x1 = cd{d02.re + j13.re, d02.im + j13.im};
+    x3 = cd{d02.re - j13.re, d02.im - j13.im};
+}
+
+// multiply by W16^e (forward) or its conjugate (inverse), e compile-time
+template <int SIGN, int E>
+__device__ __forceinline__ cd tw16(cd v)
+{
+    constexpr int e = ((E % 16) + 16) % 16;
+    if constexpr (e == 0) {
+        return v;
+    } else if constexpr (e == 4) {  // -i (fwd)
+        return SIGN < 0 ? cd{v.im, -v.re} : cd{-v.im, v.re};
+    } else if constexpr (e == 8) {
+        return cd{-v.re, -v.im};
+    } else if constexpr (e == 12) {
+        return SIGN < 0 ? cd{-v.im, v.re} : cd{v.im, -v.re};
+    } else {
+        constexpr double c = e == 1   ? 0.92387953251128673848
+                             : e == 2 ? 0.70710678118654752440
+                             : e == 3 ? 0.38268343236508977173
+                             : e == 6 ? -0.70710678118654752440
+                             : e == 9 ? -0.92387953251128673848
+                                      : 0.0;
+        constexpr double s = e == 1   ? 0.38268343236508977173
+                             : e == 2 ? 0.70710678118654752440
+                             : e == 3 ? 0.92387953251128673848
+                             : e == 6 ? 0.70710678118654752440
+                             : e == 9 ? -0.38268343236508977173
+                                      : 0.0;
+        // W16^e = c - i*s (forward); conj for inverse
+        const cd w{c, SIGN < 0 ? -s : s};
+        return cmul(v, w);
+    }
+}
+
+// 16-point DFT in place: input v[n], output v[k]   (n = j + 4i, k = m + 4p)
+template <int SIGN>
+__device__ __forceinline__ void dft16(cd (&v)[16])
+{
+    // stage 1: 4-point DFTs over i for each j  -> t[j][m] stored at v[j + 4m]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        dft4<SIGN>(v[j], v[j + 4], v[j + 8], v[j + 12]);
+    // twiddle t[j][m] *= W16^(j*m)
+    v[1 + 4 * 1] = tw16<SIGN, 1>(v[1 + 4 * 1]);
+    v[1 + 4 * 2] = tw16<SIGN, 2>(v[1 + 4 * 2]);
+    v[1 + 4 * 3] = tw16<SIGN, 3>(v[1 + 4 * 3]);
+    v[2 + 4 * 1] = tw16<SIGN, 2>(v[2 + 4 * 1]);
+    v[2 + 4 * 2] = tw16<SIGN, 4>(v[2 + 4 * 2]);
+    v[2 + 4 * 3] = tw16<SIGN, 6>(v[2 + 4 * 3]);
+    v[3 + 4 * 1] = tw16<SIGN, 3>(v[3 + 4 * 1]);
+    v[3 + 4 * 2] = tw16<SIGN, 6>(v[3 + 4 * 2]);
+    v[3 + 4 * 3] = tw16<SIGN, 9>(v[3 + 4 * 3]);
+    // stage 2: 4-point DFTs over j for each m: inputs v[j + 4m], outputs X[m + 4p]
+    // in place the result p lands at v[p + 4m]; transpose to k = m + 4p below
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        dft4<SIGN>(v[0 + 4 * m], v[1 + 4 * m], v[2 + 4 * m], v[3 + 4 * m]);
+    // v[p + 4m] holds X[m + 4p]: swap (p,m) <-> (m,p)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = p + 1; m < 4; ++m) {
+            const cd t = v[p + 4 * m];
+            v[p + 4 * m] = v[m + 4 * p];
+            v[m + 4 * p] = t;
+        }
+}
+
+struct Args {
+    int64_t frames;       // frames per Line in this call
+    int64_t line_stride;  // elements between Lines
+    int C, N, H;          // channels, taps, history frames
+    int L;                // valid outputs per tile = kM - H
+    int pairs;            // ceil(C / 2)
+    int lines;
+    int tiles_per_line;
+    int64_t nitems;       // lines * pairs * tiles_per_line
+};
+
+// Lanes of one wave talk through the wave-private buffer.  The hardware keeps a
+// wave's LDS operations in order, but the compiler reasons per thread and would
+// happily move a read above a write to a "different" address: fence every phase.
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exchange addresses (in doubles, inside the wave-private buffer)
+__device__ __forceinline__ int ex1_addr(int n1, int k2) { return 66 * k2 + n1; }
+__device__ __forceinline__ int ex2_addr(int a, int d, int k2) { return 272 * a + 17 * k2 + d; }
+
+template <typename TIn, typename TOut, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
+               const double *__restrict__ hist_base, const double2 *__restrict__ tw1_g,
+               const double2 *__restrict__ tw2_g, const double2 *__restrict__ hperm_g, const Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2 *tw1 = reinterpret_cast<double2 *>(smem_raw);           // [16][64]
+    double2 *hperm = tw1 + 16 * 64;                                  // [16][64]
+    double2 *tw2 = hperm + 16 * 64;                                  // [4][16]
+    double *exbase = reinterpret_cast<double *>(tw2 + 64);          // [WAVES][kEx]
+
+    for (int i = threadIdx.x; i < 16 * 64; i += WAVES * 64) {
+        tw1[i] = tw1_g[i];
+        hperm[i] = hperm_g[i];
+    }
+    if (threadIdx.x < 64)
+        tw2[threadIdx.x] = tw2_g[threadIdx.x];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    double *E = exbase + wave * kEx;
+    // lane roles
+    const int n1 = lane;                        // L0
+    const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
+    const int dl = lane & 15, kkl = lane >> 4;  // L2: d = lane&15, k2 = kk + 4q
+    const int64_t last = a.frames - 1;
+
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t item = wave_global; item < a.nitems; item += wave_stride) {
+        const int tile = (int)(item % a.tiles_per_line);
+        const int64_t rest = item / a.tiles_per_line;
+        const int pair = (int)(rest % a.pairs);
+        const int line = (int)(rest / a.pairs);
+        const int c0 = pair * 2;
+        const bool two = c0 + 1 < a.C;
+        const int64_t t0 = (int64_t)tile * a.L;
+        const int64_t fr0 = t0 - a.H;  // frame of window element 0
+        const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
+        const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+
+        // ---- load the window: lane n1, register n2 -> element n1 + 64*n2 --------
+        cd v[16];
+        const bool interior = fr0 >= 0 && fr0 + kM - 1 <= last && two;
+        if (interior) {
+            const TIn *__restrict__ p = in + (fr0 + n1) * a.C + c0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r].re = (double)p[(int64_t)r * 64 * a.C];
+                v[r].im = (double)p[(int64_t)r * 64 * a.C + 1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t g = fr0 + n1 + 64 * r;
+                double re = 0.0, im = 0.0;
+                if (g >= 0) {
+                    if (g <= last) {
+                        re = (double)in[g * a.C + c0];
+                        if (two)
+                            im = (double)in[g * a.C + c0 + 1];
+                    }
+                } else if (g >= -(int64_t)a.H) {
+                    re = hist[(g + a.H) * a.C + c0];
+                    if (two)
+                        im = hist[(g + a.H) * a.C + c0 + 1];
+                }
+                v[r] = cd{re, im};
+            }
+        }
+
+        // ---- forward transform -------------------------------------------------
+        dft16<-1>(v);  // A: over n2 -> k2
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {  // B
+            const double2 w = tw1[r * 64 + n1];
+            v[r] = cmul(v[r], cd{w.x, w.y});
+        }
+        // X1: (lane n1, reg k2) -> (lane k2 + 16a, reg b) holding element (a + 4b, k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex1_addr(n1, r)] = v[r].re;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].re = E[ex1_addr(al + 4 * r, k2l)];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex1_addr(n1, r)] = v[r].im;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].im = E[ex1_addr(al + 4 * r, k2l)];
+        wave_fence();
+        dft16<-1>(v);  // C1: over b -> d
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {  // C2: W64^(a*d)
+            const double2 w = tw2[al * 16 + r];
+            v[r] = cmul(v[r], cd{w.x, w.y});
+        }
+        // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex2_addr(al, r, k2l)] = v[r].re;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].re = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex2_addr(al, r, k2l)] = v[r].im;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].im = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
+        wave_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // C3: over a -> c
+            dft4<-1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+
+        // ---- spectrum of the taps (pre-permuted to this layout, scaled by 1/M) --
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double2 h = hperm[r * 64 + lane];
+            v[r] = cmul(v[r], cd{h.x, h.y});
+        }
+
+        // ---- inverse transform: the same steps backwards, conjugate twiddles -----
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = v[r].re;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].re = E[ex2_addr(al, r, k2l)];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = v[r].im;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].im = E[ex2_addr(al, r, k2l)];
+        wave_fence();
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            const double2 w = tw2[al * 16 + r];
+            v[r] = cmulc(v[r], cd{w.x, w.y});
+        }
+        dft16<+1>(v);  // over d -> b
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex1_addr(al + 4 * r, k2l)] = v[r].re;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].re = E[ex1_addr(n1, r)];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            E[ex1_addr(al + 4 * r, k2l)] = v[r].im;
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r].im = E[ex1_addr(n1, r)];
+        wave_fence();
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            const double2 w = tw1[r * 64 + n1];
+            v[r] = cmulc(v[r], cd{w.x, w.y});
+        }
+        dft16<+1>(v);  // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
+
+        // ---- store the valid part: window index i >= H is frame t0 + i - H ------
+        TOut *__restrict__ out = out_base + (int64_t)line * a.line_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = n1 + 64 * r;
+            const int64_t g = t0 + i - a.H;
+            if (i >= a.H && g <= last) {
+                out[g * a.C + c0] = (TOut)v[r].re;
+                if (two)
+                    out[g * a.C + c0 + 1] = (TOut)v[r].im;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------
+struct Plan::Impl {
+    DevBuf tw1, tw2, hperm[2];
+    int cur = 0;
+    int N = 0;
+    int cus = 256;
+};
+
+Plan::Plan() : impl_(new Impl) {}
+Plan::~Plan() { delete impl_; }
+
+bool Plan::supports(int ntaps, int channels)
+{
+    (void)channels;
+    if (std::getenv("PIPE_HIP_FIR_EXACT"))
+        return false;
+    return ntaps >= 16 && ntaps <= 512;
+}
+
+static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
+{
+    // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M), laid out as the kernel holds the
+    // spectrum: entry (r = 4q + c, lane) is frequency 256c + 16(lane & 15) + (lane >> 4) + 4q
+    std::vector<double> hr(kM), hi(kM);
+    for (int k = 0; k < kM; ++k) {
+        long double sr = 0, si = 0;
+        for (int n = 0; n < N; ++n) {
+            const int e = (int)(((int64_t)n * k) % kM);
+            const long double ang = -2.0L * (long double)kPi * e / kM;
+            sr += (long double)taps[n] * cosl(ang);
+            si += (long double)taps[n] * sinl(ang);
+        }
+        hr[k] = (double)(sr / kM);
+        hi[k] = (double)(si / kM);
+    }
+    out->assign(2 * 16 * 64, 0.0);
+    for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = r >> 2, c = r & 3;
+            const int k = 256 * c + 16 * (lane & 15) + (lane >> 4) + 4 * q;
+            (*out)[2 * (r * 64 + lane)] = hr[k];
+            (*out)[2 * (r * 64 + lane) + 1] = hi[k];
+        }
+}
+
+int Plan::init(int device, const double *taps, int ntaps)
+{
+    impl_->N = ntaps;
+    hipDeviceProp_t prop;
+    PH_HIP(hipGetDeviceProperties(&prop, device));
+    impl_->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    std::vector<double> t1(2 * 16 * 64), t2(2 * 64);
+    for (int k2 = 0; k2 < 16; ++k2)
+        for (int n1 = 0; n1 < 64; ++n1) {
+            const long double ang = -2.0L * (long double)kPi * (n1 * k2) / kM;
+            t1[2 * (k2 * 64 + n1)] = (double)cosl(ang);
+            t1[2 * (k2 * 64 + n1) + 1] = (double)sinl(ang);
+        }
+    for (int a = 0; a < 4; ++a)
+        for (int d = 0; d < 16; ++d) {
+            const long double ang = -2.0L * (long double)kPi * (a * d) / 64;
+            t2[2 * (a * 16 + d)] = (double)cosl(ang);
+            t2[2 * (a * 16 + d) + 1] = (double)sinl(ang);
+        }
+    PH_TRY(impl_->tw1.alloc(sizeof(double) * t1.size()));
+    PH_TRY(impl_->tw2.alloc(sizeof(double) * t2.size()));
+    PH_TRY(impl_->hperm[0].alloc(sizeof(double) * 2 * 16 * 64));
+    PH_TRY(impl_->hperm[1].alloc(sizeof(double) * 2 * 16 * 64));
+    PH_HIP(hipMemcpy(impl_->tw1.p, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
+    PH_HIP(hipMemcpy(impl_->tw2.p, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
+    return set_taps(taps);
+}
+
+int Plan::set_taps(const double *taps)
+{
+    std::vector<double> h;
+    tap_spectrum(taps, impl_->N, &h);
+    const int nxt = impl_->cur ^ 1;
+    PH_HIP(hipMemcpy(impl_->hperm[nxt].p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    impl_->cur = nxt;
+    return PIPE_HIP_OK;
+}
+
+int64_t Plan::items(int64_t frames, int channels, int lines) const
+{
+    const int L = kM - (impl_->N - 1);
+    return ((frames + L - 1) / L) * ((channels + 1) / 2) * (int64_t)lines;
+}
+
+template <typename TIn, typename TOut, int WAVES>
+static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, const Args &a,
+                      hipStream_t s)
+{
+    auto kfn = fir_ols_kernel<TIn, TOut, WAVES>;
+    const size_t lds = sizeof(double2) * (16 * 64 * 2 + 64) + sizeof(double) * (size_t)kEx * WAVES;
+    if (lds > 64 * 1024)
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, WAVES * 64, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int64_t slots = (int64_t)per_cu * I.cus * WAVES;  // resident waves
+    const int64_t per = (a.nitems + slots - 1) / slots;     // items per wave
+    const int64_t waves = (a.nitems + per - 1) / per;
+    const unsigned grid = (unsigned)((waves + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, s, static_cast<const TIn *>(d_in),
+                       static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw1.p),
+                       static_cast<const double2 *>(I.tw2.p), static_cast<const double2 *>(I.hperm[I.cur].p), a);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
+int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, int64_t frames,
+              int channels, int lines, hipStream_t s, const char **kernel_name)
+{
+    Args a{};
+    a.frames = frames;
+    a.line_stride = frames * channels;
+    a.C = channels;
+    a.N = impl_->N;
+    a.H = impl_->N - 1;
+    a.L = kM - a.H;
+    a.pairs = (channels + 1) / 2;
+    a.lines = lines;
+    a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
+    a.nitems = (int64_t)a.tiles_per_line * a.pairs * lines;
+    constexpr int W = 8;
+    if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+        *kernel_name = "fir_ols_kernel<f32,f32>";
+        return launch_ols<float, float, W>(*impl_, d_in, d_out, hist, a, s);
+    }
+    if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
+        *kernel_name = "fir_ols_kernel<f64,f32>";
+        return launch_ols<double, float, W>(*impl_, d_in, d_out, hist, a, s);
+    }
+    return PIPE_HIP_EINVAL;
+}
+
+}  // namespace ols
+}  // namespace pipehip

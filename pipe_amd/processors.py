@@ -192,6 +192,11 @@ class Fir(Processor):
     def set_taps(self, taps):
         self._set_param(L.PARAM_TAPS, taps)
 
+    def set_exact(self, exact: bool):
+        """True pins the ordered-fma direct form (bit-exact); False (default) lets large
+        float32 batches use the overlap-save FFT form (<= 1 ulp float32)."""
+        self._set_param(L.PARAM_EXACT, [1.0 if exact else 0.0])
+
 
 class Biquad(Processor):
     def __init__(self, coeffs, buffer_size: int, channels: int, **kw):

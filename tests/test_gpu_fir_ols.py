@@ -1,0 +1,134 @@
+"""The overlap-save (float64 FFT) form of the FIR Processor.
+
+Tolerance (north_star: "within 1 ULP float32"), written out: for float32 buffers
+    |gpu - (float)oracle_f64| <= 1 ulp_f32( max(|oracle|, 2^-24 * ||h||_1 * max|x|) )
+i.e. one float32 ulp, measured no finer than 24 bits below the filter's full-scale
+output (below that the oracle's own ordered sum is uncertain by N*2^-53*||h||_1).
+The direct form stays bit-exact and is what float64 buffers, small calls and
+PIPE_HIP_PARAM_EXACT use; both are checked against each other here.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P = None
+torch = None
+
+
+def setup_module(module):
+    global P, torch
+    import torch as _t
+    from pipe_amd import processors as _p
+    assert _t.cuda.is_available()
+    P, torch = _p, _t
+
+
+def ulp_diff_f32(got, want64, floor_mag):
+    """|got - want| in units of the float32 ulp at max(|want|, floor_mag)."""
+    want32 = want64.astype(np.float32)
+    mag = np.maximum(np.abs(want64), floor_mag).astype(np.float32)
+    ulp = np.spacing(mag).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want32.astype(np.float64)) / ulp
+
+
+def run_batch(taps, x, F, K, lines, exact):
+    C = x.shape[-1]
+    with P.Fir(taps, F, C, dtype=np.float32, lines=lines, max_batch=K) as p:
+        p.start()
+        if exact:
+            p.set_exact(True)
+        d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        d_out = torch.empty_like(d_in)
+        outs = []
+        half = (K // 2) * F
+        # two launches: history must carry between them in this form too
+        frames = x.shape[-2]
+        for a, b in ((0, half), (half, frames)):
+            xin = d_in[..., a:b, :].contiguous()
+            yout = torch.empty_like(xin)
+            p.process_batch(xin, yout, b - a)
+            outs.append(yout)
+        torch.cuda.synchronize()
+        name = p.kernel_name()
+        return torch.cat(outs, dim=-2).cpu().numpy(), name
+
+
+@pytest.mark.parametrize("channels,ntaps", [(2, 256), (2, 64), (2, 511), (4, 256), (3, 256), (1, 128)])
+def test_ols_within_one_ulp_of_oracle_and_of_direct_form(channels, ntaps, monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")  # take the FFT form even for this small batch
+    F, K, lines = 1024, 24, 2
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    x = np.stack([synth.samples(synth.line_seed(50 + l), 0, K * F * channels, np.float32).reshape(K * F, channels)
+                  for l in range(lines)])
+    got, name = run_batch(taps, x, F, K, lines, exact=False)
+    assert "fir_ols_kernel" in name
+    ref, name2 = run_batch(taps, x, F, K, lines, exact=True)
+    assert "fir_direct_kernel" in name2
+    floor = 2.0 ** -24 * np.abs(taps).sum() * 1.0
+    for l in range(lines):
+        want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(K * F, channels)
+        assert np.array_equal(ref[l], want.astype(np.float32))  # direct form: bit-exact
+        d = ulp_diff_f32(got[l], want, floor)
+        assert d.max() <= 1.0, f"line {l}: max {d.max()} ulp"
+        # and almost always it is the very same float32
+        assert np.mean(got[l] != want.astype(np.float32)) < 1e-4
+
+
+def test_ols_impulse_and_linearity_properties(monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    F, K, C, N = 4096, 64, 2, 256
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    n = K * F
+    x = np.zeros((n, C), np.float32)
+    pos = 100_000
+    x[pos, 0] = 1.0
+    x[pos + 7, 1] = -0.5
+    with P.Fir(taps, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        p.process_batch(d_in, d_out, n)
+        torch.cuda.synchronize()
+        assert "fir_ols_kernel" in p.kernel_name()
+        y = d_out.cpu().numpy()
+    h32 = taps.astype(np.float32)
+    # impulse response == taps to float32 rounding (1 ulp), zeros elsewhere up to FFT noise
+    assert np.max(np.abs(y[pos:pos + N, 0] - h32)) <= np.spacing(np.abs(h32).max())
+    assert np.max(np.abs(y[pos + 7:pos + 7 + N, 1] + 0.5 * h32)) <= np.spacing(np.abs(h32).max())
+    mask = np.ones(n, bool)
+    mask[pos:pos + N + 7] = False
+    assert np.max(np.abs(y[mask])) < 1e-14
+
+
+def test_ols_set_taps_and_restart(monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    F, K, C = 2048, 8, 2
+    h1 = synth.fir_lowpass_taps(128, f32_rounded=True)
+    h2 = synth.fir_lowpass_taps(128, fc=0.1, f32_rounded=True)
+    x = synth.samples(synth.line_seed(60), 0, 2 * K * F * C, np.float32).reshape(2 * K * F, C)
+    ref = O.Fir(h1, C)
+    floor = 2.0 ** -24 * max(np.abs(h1).sum(), np.abs(h2).sum())
+    with P.Fir(h1, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        p.process_batch(d_in[:K * F], d_out[:K * F], K * F)
+        p.set_taps(h2)  # mutation: history is kept, the next batch uses the new spectrum
+        p.process_batch(d_in[K * F:], d_out[K * F:], K * F)
+        torch.cuda.synchronize()
+        y = d_out.cpu().numpy()
+        w1 = ref.process(x[:K * F].astype(np.float64)).reshape(-1, C)
+        ref.set_taps(h2)
+        w2 = ref.process(x[K * F:].astype(np.float64)).reshape(-1, C)
+        assert ulp_diff_f32(y[:K * F], w1, floor).max() <= 1.0
+        assert ulp_diff_f32(y[K * F:], w2, floor).max() <= 1.0
+        p.start()  # StartFunc: history zeroed
+        p.process_batch(d_in[:K * F], d_out[:K * F], K * F)
+        torch.cuda.synchronize()
+        ref2 = O.Fir(h2, C)
+        w3 = ref2.process(x[:K * F].astype(np.float64)).reshape(-1, C)
+        assert ulp_diff_f32(d_out[:K * F].cpu().numpy(), w3, floor).max() <= 1.0
