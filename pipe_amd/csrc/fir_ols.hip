@@ -17,8 +17,8 @@
 // Mapping: ONE WAVE = one 1024-point complex FFT, held as 16 complex values per
 // lane.  1024 = 16 x 16 x 4:
 //     A  : 16-point DFT in registers over n2           (n = n1 + 64*n2, lane = n1)
-//     B  : twiddle W1024^(n1*k2)                        (table in LDS)
-//     X1 : wave-private LDS exchange (conflict-free strides 66 / 1)
+//     B  : twiddle W1024^(n1*k2)        (powers of one per-lane register constant)
+//     X1 : wave-private LDS exchange of complex values (16 B, strides 65 / 1)
 //     C1 : 16-point DFT in registers over b             (n1 = a + 4*b)
 //     C2 : twiddle W64^(a*d)
 //     X2 : wave-private LDS exchange (strides 272 / 17 / 1)
@@ -39,7 +39,7 @@ namespace ols {
 namespace {
 
 constexpr int kM = 1024;         // FFT size
-constexpr int kEx = 1088;        // doubles per wave-private exchange buffer
+constexpr int kEx = 1088;        // complex elements per wave-private exchange buffer
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
 struct cd {
@@ -143,6 +143,45 @@ __device__ __forceinline__ void dft16(cd (&v)[16])
         }
 }
 
+// v[k] *= w^k for k = 1..15 from the one per-lane constant w (|w| = 1): no twiddle
+// table and no LDS traffic.  Powers are built in groups of four off w, w^2, w^3 so
+// that at most five of them are live at once (register pressure), and no power is
+// more than five complex multiplications away from w (rounding error).
+__device__ __forceinline__ void apply_powers(cd (&v)[16], const cd w)
+{
+    const cd w2 = cmul(w, w);
+    const cd w3 = cmul(w2, w);
+    v[1] = cmul(v[1], w);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    cd b = cmul(w2, w2);  // w^4
+    v[4] = cmul(v[4], b);
+    v[5] = cmul(v[5], cmul(b, w));
+    v[6] = cmul(v[6], cmul(b, w2));
+    v[7] = cmul(v[7], cmul(b, w3));
+    b = cmul(b, b);  // w^8
+    v[8] = cmul(v[8], b);
+    v[9] = cmul(v[9], cmul(b, w));
+    v[10] = cmul(v[10], cmul(b, w2));
+    v[11] = cmul(v[11], cmul(b, w3));
+    b = cmul(b, cmul(w2, w2));  // w^12
+    v[12] = cmul(v[12], b);
+    v[13] = cmul(v[13], cmul(b, w));
+    v[14] = cmul(v[14], cmul(b, w2));
+    v[15] = cmul(v[15], cmul(b, w3));
+}
+
+template <typename T>
+struct Pair;
+template <>
+struct Pair<float> {
+    using type = float2;
+};
+template <>
+struct Pair<double> {
+    using type = double2;
+};
+
 struct Args {
     int64_t frames;       // frames per Line in this call
     int64_t line_stride;  // elements between Lines
@@ -165,56 +204,99 @@ __device__ __forceinline__ void wave_fence()
 }
 
 // exchange addresses (in doubles, inside the wave-private buffer)
-__device__ __forceinline__ int ex1_addr(int n1, int k2) { return 66 * k2 + n1; }
+// (strides are odd so that the 16-lane groups of ds_read2_b64 / ds_write_b64 fall on 16 distinct
+// 8-byte slots)
+__device__ __forceinline__ int ex1_addr(int n1, int k2) { return 65 * k2 + n1; }
 __device__ __forceinline__ int ex2_addr(int a, int d, int k2) { return 272 * a + 17 * k2 + d; }
 
-template <typename TIn, typename TOut, int WAVES>
+// VEC: the channel count is even, so a channel pair is one naturally aligned 8/16-byte
+// element: window loads and result stores move whole pairs, and the next item's window is
+// prefetched into registers while the current one is transformed.
+template <typename TIn, typename TOut, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64)
 fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                const double *__restrict__ hist_base, const double2 *__restrict__ tw1_g,
                const double2 *__restrict__ tw2_g, const double2 *__restrict__ hperm_g, const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double2 *tw1 = reinterpret_cast<double2 *>(smem_raw);           // [16][64]
-    double2 *hperm = tw1 + 16 * 64;                                  // [16][64]
-    double2 *tw2 = hperm + 16 * 64;                                  // [4][16]
-    double *exbase = reinterpret_cast<double *>(tw2 + 64);          // [WAVES][kEx]
+    double2 *hperm = reinterpret_cast<double2 *>(smem_raw);  // [16][64] tap spectrum, kernel layout
+    double2 *exbase = hperm + 16 * 64;                       // [WAVES][kEx] wave-private exchange
 
-    for (int i = threadIdx.x; i < 16 * 64; i += WAVES * 64) {
-        tw1[i] = tw1_g[i];
+    for (int i = threadIdx.x; i < 16 * 64; i += WAVES * 64)
         hperm[i] = hperm_g[i];
-    }
-    if (threadIdx.x < 64)
-        tw2[threadIdx.x] = tw2_g[threadIdx.x];
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    double *E = exbase + wave * kEx;
+    double2 *E = exbase + wave * kEx;
     // lane roles
     const int n1 = lane;                        // L0
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
     const int dl = lane & 15, kkl = lane >> 4;  // L2: d = lane&15, k2 = kk + 4q
     const int64_t last = a.frames - 1;
+    // per-lane twiddle seeds: W1024^n1 (step B) and W64^a (step C2)
+    const double2 s1 = tw1_g[64 + n1];
+    const double2 s2 = tw2_g[al * 16 + 1];
+    cd wB{s1.x, s1.y};
+    cd wC{s2.x, s2.y};
 
-    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
-    for (int64_t item = wave_global; item < a.nitems; item += wave_stride) {
+    using In2 = typename Pair<TIn>::type;
+    using Out2 = typename Pair<TOut>::type;
+    struct Item {
+        int line, c0;
+        bool two, interior;
+        int64_t t0, fr0;
+    };
+    auto decode = [&](int64_t item) {
+        Item it;
         const int tile = (int)(item % a.tiles_per_line);
         const int64_t rest = item / a.tiles_per_line;
         const int pair = (int)(rest % a.pairs);
-        const int line = (int)(rest / a.pairs);
-        const int c0 = pair * 2;
-        const bool two = c0 + 1 < a.C;
-        const int64_t t0 = (int64_t)tile * a.L;
-        const int64_t fr0 = t0 - a.H;  // frame of window element 0
+        it.line = (int)(rest / a.pairs);
+        it.c0 = pair * 2;
+        it.two = it.c0 + 1 < a.C;
+        it.t0 = (int64_t)tile * a.L;
+        it.fr0 = it.t0 - a.H;  // frame of window element 0
+        it.interior = it.fr0 >= 0 && it.fr0 + kM - 1 <= last && it.two;
+        return it;
+    };
+    // pair loads of an interior window: lane n1, register r -> frame fr0 + n1 + 64 r
+    In2 pf[16];
+    auto issue = [&](const Item &it) {
+        const In2 *__restrict__ p = reinterpret_cast<const In2 *>(
+            in_base + (int64_t)it.line * a.line_stride + (it.fr0 + n1) * a.C + it.c0);
+        const int64_t step = (int64_t)32 * a.C;  // 64 frames, in pairs
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pf[r] = p[r * step];
+    };
+
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
+    Item cur = decode(wave_global < a.nitems ? wave_global : 0);
+    bool have_pf = false;
+    if (VEC && wave_global < a.nitems && cur.interior) {
+        issue(cur);
+        have_pf = true;
+    }
+    for (int64_t item = wave_global; item < a.nitems; item += wave_stride) {
+        // the seeds are loop-invariant; without this the compiler hoists all 60 of their
+        // powers out of the item loop and spills them
+        asm volatile("" : "+v"(wB.re), "+v"(wB.im), "+v"(wC.re), "+v"(wC.im));
+        const cd wBc{wB.re, -wB.im}, wCc{wC.re, -wC.im};
+        const int line = cur.line, c0 = cur.c0;
+        const bool two = cur.two;
+        const int64_t t0 = cur.t0, fr0 = cur.fr0;
         const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
         const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
 
-        // ---- load the window: lane n1, register n2 -> element n1 + 64*n2 --------
+        // ---- the window: lane n1, register n2 -> element n1 + 64*n2 -------------
         cd v[16];
-        const bool interior = fr0 >= 0 && fr0 + kM - 1 <= last && two;
-        if (interior) {
+        if (have_pf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = cd{(double)pf[r].x, (double)pf[r].y};
+        } else if (cur.interior) {
             const TIn *__restrict__ p = in + (fr0 + n1) * a.C + c0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -240,53 +322,42 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 v[r] = cd{re, im};
             }
         }
+        // next item's window: in flight while this one is transformed
+        have_pf = false;
+        if (item + wave_stride < a.nitems) {
+            cur = decode(item + wave_stride);
+            if (VEC && cur.interior) {
+                issue(cur);
+                have_pf = true;
+            }
+        }
 
         // ---- forward transform -------------------------------------------------
-        dft16<-1>(v);  // A: over n2 -> k2
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {  // B
-            const double2 w = tw1[r * 64 + n1];
-            v[r] = cmul(v[r], cd{w.x, w.y});
-        }
+        dft16<-1>(v);    // A: over n2 -> k2
+        apply_powers(v, wB);       // B: W1024^(n1*k2)
         // X1: (lane n1, reg k2) -> (lane k2 + 16a, reg b) holding element (a + 4b, k2)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            E[ex1_addr(n1, r)] = v[r].re;
+            E[ex1_addr(n1, r)] = double2{v[r].re, v[r].im};
         wave_fence();
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].re = E[ex1_addr(al + 4 * r, k2l)];
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex1_addr(n1, r)] = v[r].im;
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].im = E[ex1_addr(al + 4 * r, k2l)];
-        wave_fence();
-        dft16<-1>(v);  // C1: over b -> d
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {  // C2: W64^(a*d)
-            const double2 w = tw2[al * 16 + r];
-            v[r] = cmul(v[r], cd{w.x, w.y});
+        for (int r = 0; r < 16; ++r) {
+            const double2 t = E[ex1_addr(al + 4 * r, k2l)];
+            v[r] = cd{t.x, t.y};
         }
+        wave_fence();
+        dft16<-1>(v);    // C1: over b -> d
+        apply_powers(v, wC);       // C2: W64^(a*d)
         // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            E[ex2_addr(al, r, k2l)] = v[r].re;
+            E[ex2_addr(al, r, k2l)] = double2{v[r].re, v[r].im};
         wave_fence();
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].re = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex2_addr(al, r, k2l)] = v[r].im;
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].im = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
+        for (int r = 0; r < 16; ++r) {
+            const double2 t = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
+            v[r] = cd{t.x, t.y};
+        }
         wave_fence();
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
@@ -305,48 +376,28 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = v[r].re;
+            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = double2{v[r].re, v[r].im};
         wave_fence();
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].re = E[ex2_addr(al, r, k2l)];
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = v[r].im;
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].im = E[ex2_addr(al, r, k2l)];
-        wave_fence();
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            const double2 w = tw2[al * 16 + r];
-            v[r] = cmulc(v[r], cd{w.x, w.y});
+        for (int r = 0; r < 16; ++r) {
+            const double2 t = E[ex2_addr(al, r, k2l)];
+            v[r] = cd{t.x, t.y};
         }
-        dft16<+1>(v);  // over d -> b
+        wave_fence();
+        apply_powers(v, wCc);
+        dft16<+1>(v);    // over d -> b
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            E[ex1_addr(al + 4 * r, k2l)] = v[r].re;
+            E[ex1_addr(al + 4 * r, k2l)] = double2{v[r].re, v[r].im};
         wave_fence();
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].re = E[ex1_addr(n1, r)];
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex1_addr(al + 4 * r, k2l)] = v[r].im;
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r].im = E[ex1_addr(n1, r)];
-        wave_fence();
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            const double2 w = tw1[r * 64 + n1];
-            v[r] = cmulc(v[r], cd{w.x, w.y});
+        for (int r = 0; r < 16; ++r) {
+            const double2 t = E[ex1_addr(n1, r)];
+            v[r] = cd{t.x, t.y};
         }
-        dft16<+1>(v);  // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
+        wave_fence();
+        apply_powers(v, wBc);
+        dft16<+1>(v);    // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
 
         // ---- store the valid part: window index i >= H is frame t0 + i - H ------
         TOut *__restrict__ out = out_base + (int64_t)line * a.line_stride;
@@ -355,9 +406,16 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             const int i = n1 + 64 * r;
             const int64_t g = t0 + i - a.H;
             if (i >= a.H && g <= last) {
-                out[g * a.C + c0] = (TOut)v[r].re;
-                if (two)
-                    out[g * a.C + c0 + 1] = (TOut)v[r].im;
+                if (VEC && two) {
+                    Out2 o;
+                    o.x = (TOut)v[r].re;
+                    o.y = (TOut)v[r].im;
+                    *reinterpret_cast<Out2 *>(out + g * a.C + c0) = o;
+                } else {
+                    out[g * a.C + c0] = (TOut)v[r].re;
+                    if (two)
+                        out[g * a.C + c0 + 1] = (TOut)v[r].im;
+                }
             }
         }
     }
@@ -454,12 +512,12 @@ int64_t Plan::items(int64_t frames, int channels, int lines) const
     return ((frames + L - 1) / L) * ((channels + 1) / 2) * (int64_t)lines;
 }
 
-template <typename TIn, typename TOut, int WAVES>
+template <typename TIn, typename TOut, int WAVES, bool VEC>
 static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, const Args &a,
                       hipStream_t s)
 {
-    auto kfn = fir_ols_kernel<TIn, TOut, WAVES>;
-    const size_t lds = sizeof(double2) * (16 * 64 * 2 + 64) + sizeof(double) * (size_t)kEx * WAVES;
+    auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
+    const size_t lds = sizeof(double2) * (16 * 64) + sizeof(double2) * (size_t)kEx * WAVES;
     if (lds > 64 * 1024)
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -493,14 +551,23 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
     a.nitems = (int64_t)a.tiles_per_line * a.pairs * lines;
-    constexpr int W = 8;
+    // pairs are naturally aligned when the channel count is even and the buffers are
+    const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    const char *wenv = std::getenv("PIPE_HIP_OLS_WAVES");  // tuning knob
+    const int W = wenv ? std::atoi(wenv) : 8;
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32>";
-        return launch_ols<float, float, W>(*impl_, d_in, d_out, hist, a, s);
+        (void)W;
+        if (vec)
+            return launch_ols<float, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
+        return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f64,f32>";
-        return launch_ols<double, float, W>(*impl_, d_in, d_out, hist, a, s);
+        if (vec)
+            return launch_ols<double, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
+        return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     return PIPE_HIP_EINVAL;
 }
