@@ -132,3 +132,41 @@ def test_ols_set_taps_and_restart(monkeypatch):
         ref2 = O.Fir(h2, C)
         w3 = ref2.process(x[:K * F].astype(np.float64)).reshape(-1, C)
         assert ulp_diff_f32(d_out[:K * F].cpu().numpy(), w3, floor).max() <= 1.0
+
+
+def test_ols_full_bench_size_against_bit_exact_form():
+    # BASELINE-size stream (1 Line x 2 ch x 4096 buffers of 4096 frames, float32, 256 taps):
+    # the overlap-save form against the bit-exact direct form on the device, every sample.
+    F, K, C, N = 4096, 4096, 2, 256
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    n = K * F * C
+    d_in = torch.empty(n, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(0))
+    y_ols = torch.empty_like(d_in)
+    y_ref = torch.empty_like(d_in)
+    with P.Fir(taps, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        p.process_batch(d_in, y_ols, K * F)
+        torch.cuda.synchronize()
+        assert "fir_ols_kernel" in p.kernel_name()
+        p.start()
+        p.set_exact(True)
+        p.process_batch(d_in, y_ref, K * F)
+        torch.cuda.synchronize()
+        assert "fir_direct_kernel" in p.kernel_name()
+    floor = float(np.float32(2.0 ** -24 * np.abs(taps).sum()))
+    differ = y_ols != y_ref
+    n_diff = int(differ.sum().item())
+    # ulp distance through the ordered-integer view of IEEE floats
+    def key(t):
+        i = t.view(torch.int32).to(torch.int64)
+        return torch.where(i < 0, -(i & 0x7FFFFFFF), i)
+    big = y_ref.abs() >= floor
+    ulps = (key(y_ols) - key(y_ref)).abs()
+    max_ulp_big = int(ulps[big].max().item())
+    small_abs = float((y_ols - y_ref).abs()[~big].max().item()) if int((~big).sum().item()) else 0.0
+    print(f"\n[ols vs bit-exact] samples={n} differ={n_diff} ({n_diff / n:.2e}) max_ulp={max_ulp_big} "
+          f"below-floor={int((~big).sum().item())} max_abs_below_floor={small_abs:.3e}")
+    assert max_ulp_big <= 1
+    assert small_abs <= float(np.spacing(np.float32(floor)))
+    assert n_diff / n < 1e-5
