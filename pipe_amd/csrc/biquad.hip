@@ -6,110 +6,121 @@
 //     s2 = fma(-a2, y, b2 * x)
 // An IIR is a serial recurrence along time, so the only parallelism that keeps
 // the float64 result bit-exact is across (Line, channel) series: one lane per
-// series.  A wave stages kChunk frames of its series through LDS (coalesced
-// global access, all lanes of the workgroup cooperating), then each lane walks
-// its own recurrence out of LDS.  The kernel is latency-bound by the dependent
-// fma chain (2 fma on the critical path per section and sample), not by HBM.
+// series, state in registers for the whole call.  The kernel is bound by the
+// latency of the dependent fma chain (2 fma on the critical path per section and
+// sample), not by HBM: what matters is that memory never adds to that chain, so
+// each lane issues kChunk independent loads before it starts the kChunk dependent
+// steps, and stores the results afterwards.  The channels of a Line are adjacent
+// in memory, so a wave's accesses are C-element runs that L2 merges into lines.
+// An optional gain (the stage that follows a biquad in BASELINE config 3) is
+// applied to the float64 result in the same pass: y_out = y * g, exactly the
+// arithmetic of a separate gain stage reading float64.
 #include "common.hpp"
 
 namespace pipehip {
 namespace {
 
 constexpr int kMaxSections = 8;
-constexpr int kThreads = 64;  // one wave per workgroup: series are scarce, spread them over CUs
-constexpr int kChunk = 64;    // frames staged per trip
+constexpr int kThreads = 64;
+constexpr int kChunk = 16;  // frames in flight per lane
 
 struct BiquadCoeffs {
     double c[kMaxSections][5];
 };
 
 struct BiquadArgs {
-    const void *in;
-    void *out;
     double *state;  // [lines][C][S][2]
     int64_t frames;
-    int C, S, lines;
-    int spb;        // series per workgroup (<= kThreads), a multiple of C or a divisor arrangement
+    int C, S, nseries;
+    int has_gain;
+    double gain;
 };
 
-// Workgroup b owns series [b*spb, b*spb + spb) where series id = line*C + c.
-// Because the layout is (line, frame, channel), the series of one Line are
-// contiguous within a frame: a chunk of one Line is a dense [kChunk][C] block.
-template <typename TIn, typename TOut>
-__global__ void __launch_bounds__(kThreads) biquad_kernel(const BiquadArgs a, const BiquadCoeffs q)
+template <int NS>
+__device__ __forceinline__ double biquad_step(double x, double (&s1)[kMaxSections],
+                                              double (&s2)[kMaxSections], const BiquadCoeffs &q)
 {
-    __shared__ double tile[kThreads * (kChunk + 1)];
-    const int series0 = blockIdx.x * a.spb;
-    const int nseries_total = a.lines * a.C;
-    const int nser = min(a.spb, nseries_total - series0);
-    const int lane = threadIdx.x;
-    const bool owner = lane < nser;
-    const int my = series0 + lane;
-    const int my_line = owner ? my / a.C : 0;
-    const int my_c = owner ? my - my_line * a.C : 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double y = __builtin_fma(q.c[s][0], x, s1[s]);
+        const double t = __builtin_fma(q.c[s][1], x, s2[s]);
+        s1[s] = __builtin_fma(-q.c[s][3], y, t);
+        const double u = q.c[s][2] * x;
+        s2[s] = __builtin_fma(-q.c[s][4], y, u);
+        x = y;
+    }
+    return x;
+}
+
+// NS = compile-time section count (1, 2) or 0 = runtime a.S
+template <typename TIn, typename TOut, int NS>
+__global__ void __launch_bounds__(kThreads)
+biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a,
+              const BiquadCoeffs q)
+{
+    const int sid = blockIdx.x * kThreads + threadIdx.x;
+    if (sid >= a.nseries)
+        return;
+    const int line = sid / a.C;
+    const int c = sid - line * a.C;
+    const TIn *__restrict__ in = in_base + (int64_t)line * a.frames * a.C + c;
+    TOut *__restrict__ out = out_base + (int64_t)line * a.frames * a.C + c;
+    double *__restrict__ st = a.state + (int64_t)sid * a.S * 2;
 
     double s1[kMaxSections], s2[kMaxSections];
 #pragma unroll
     for (int s = 0; s < kMaxSections; ++s) {
         s1[s] = 0.0;
         s2[s] = 0.0;
-    }
-    if (owner) {
-        for (int s = 0; s < a.S; ++s) {
-            const double *st = a.state + (((int64_t)my_line * a.C + my_c) * a.S + s) * 2;
-            s1[s] = st[0];
-            s2[s] = st[1];
+        if (s < a.S) {
+            s1[s] = st[2 * s];
+            s2[s] = st[2 * s + 1];
         }
     }
-    const TIn *__restrict__ in = reinterpret_cast<const TIn *>(a.in);
-    TOut *__restrict__ out = reinterpret_cast<TOut *>(a.out);
-
-    for (int64_t f0 = 0; f0 < a.frames; f0 += kChunk) {
-        const int nf = (int)min((int64_t)kChunk, a.frames - f0);
-        // stage: element e -> (series j, frame f) with the channel index fastest
-        // in memory: for a Line, [f][c] is dense
-        for (int e = lane; e < nser * nf; e += kThreads) {
-            // walk memory order: per line segment [nf][cseg]
-            const int j = e % nser;       // series within the workgroup
-            const int f = e / nser;
-            const int sid = series0 + j;
-            const int l = sid / a.C, c = sid - l * a.C;
-            tile[j * (kChunk + 1) + f] = (double)in[((int64_t)l * a.frames + f0 + f) * a.C + c];
-        }
-        __syncthreads();
-        if (owner) {
-            double *row = tile + lane * (kChunk + 1);
-            for (int f = 0; f < nf; ++f) {
-                double x = row[f];
+    auto step = [&](double x) -> double {
+        double y;
+        if constexpr (NS > 0) {
+            y = biquad_step<NS>(x, s1, s2, q);
+        } else {
+            y = x;
 #pragma unroll
-                for (int s = 0; s < kMaxSections; ++s) {
-                    if (s < a.S) {
-                        const double y = __builtin_fma(q.c[s][0], x, s1[s]);
-                        const double t = __builtin_fma(q.c[s][1], x, s2[s]);
-                        s1[s] = __builtin_fma(-q.c[s][3], y, t);
-                        const double u = q.c[s][2] * x;
-                        s2[s] = __builtin_fma(-q.c[s][4], y, u);
-                        x = y;
-                    }
+            for (int s = 0; s < kMaxSections; ++s) {
+                if (s < a.S) {
+                    const double v = __builtin_fma(q.c[s][0], y, s1[s]);
+                    const double t = __builtin_fma(q.c[s][1], y, s2[s]);
+                    s1[s] = __builtin_fma(-q.c[s][3], v, t);
+                    const double u = q.c[s][2] * y;
+                    s2[s] = __builtin_fma(-q.c[s][4], v, u);
+                    y = v;
                 }
-                row[f] = x;
             }
         }
-        __syncthreads();
-        for (int e = lane; e < nser * nf; e += kThreads) {
-            const int j = e % nser;
-            const int f = e / nser;
-            const int sid = series0 + j;
-            const int l = sid / a.C, c = sid - l * a.C;
-            out[((int64_t)l * a.frames + f0 + f) * a.C + c] = (TOut)tile[j * (kChunk + 1) + f];
-        }
-        __syncthreads();
+        return a.has_gain ? y * a.gain : y;
+    };
+
+    const int64_t stride = a.C;
+    int64_t f = 0;
+    for (; f + kChunk <= a.frames; f += kChunk) {
+        TIn x[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+            x[u] = in[(f + u) * stride];
+        TOut y[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+            y[u] = (TOut)step((double)x[u]);
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+            out[(f + u) * stride] = y[u];
     }
-    if (owner) {
-        for (int s = 0; s < a.S; ++s) {
-            double *st = a.state + (((int64_t)my_line * a.C + my_c) * a.S + s) * 2;
-            st[0] = s1[s];
-            st[1] = s2[s];
+    for (; f < a.frames; ++f)
+        out[f * stride] = (TOut)step((double)in[f * stride]);
+
+#pragma unroll
+    for (int s = 0; s < kMaxSections; ++s) {
+        if (s < a.S) {
+            st[2 * s] = s1[s];
+            st[2 * s + 1] = s2[s];
         }
     }
 }
@@ -137,42 +148,51 @@ public:
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
         return PIPE_HIP_OK;
     }
+    // a gain stage that directly follows this biquad in a chain is folded into the
+    // store of the result (same float64 arithmetic as the separate stage)
+    void set_post_gain(bool on, double g)
+    {
+        has_gain_ = on;
+        gain_ = g;
+    }
+
     int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
             hipStream_t s) override
     {
         if (frames <= 0)
             return PIPE_HIP_OK;
         BiquadArgs a{};
-        a.in = d_in;
-        a.out = d_out;
         a.state = static_cast<double *>(state_.p);
         a.frames = frames;
         a.C = cfg.channels;
         a.S = S_;
-        a.lines = cfg.lines;
-        const int nseries = cfg.lines * cfg.channels;
-        // spread series over the chip: aim at >= 256 workgroups before packing lanes
-        int spb = (nseries + 255) / 256;
-        if (spb < 1)
-            spb = 1;
-        if (spb > kThreads)
-            spb = kThreads;
-        a.spb = spb;
-        const dim3 grid((unsigned)((nseries + spb - 1) / spb));
+        a.nseries = cfg.lines * cfg.channels;
+        a.has_gain = has_gain_ ? 1 : 0;
+        a.gain = gain_;
+        const dim3 grid((unsigned)((a.nseries + kThreads - 1) / kThreads));
         PH_TRY(timer.begin(s));
-        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
-            hipLaunchKernelGGL((biquad_kernel<float, float>), grid, dim3(kThreads), 0, s, a, q_);
-            last_kernel = "biquad_kernel<f32,f32>";
-        } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
-            hipLaunchKernelGGL((biquad_kernel<double, double>), grid, dim3(kThreads), 0, s, a, q_);
-            last_kernel = "biquad_kernel<f64,f64>";
-        } else if (in_dtype == PIPE_HIP_F32) {
-            hipLaunchKernelGGL((biquad_kernel<float, double>), grid, dim3(kThreads), 0, s, a, q_);
-            last_kernel = "biquad_kernel<f32,f64>";
-        } else {
-            hipLaunchKernelGGL((biquad_kernel<double, float>), grid, dim3(kThreads), 0, s, a, q_);
-            last_kernel = "biquad_kernel<f64,f32>";
-        }
+#define PH_BQ(TI, TO, NAME)                                                                         \
+    do {                                                                                            \
+        if (S_ == 1)                                                                                \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 1>), grid, dim3(kThreads), 0, s,              \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
+        else if (S_ == 2)                                                                           \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 2>), grid, dim3(kThreads), 0, s,              \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
+        else                                                                                        \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 0>), grid, dim3(kThreads), 0, s,              \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
+        last_kernel = NAME;                                                                         \
+    } while (0)
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+            PH_BQ(float, float, "biquad_kernel<f32,f32>");
+        else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+            PH_BQ(double, double, "biquad_kernel<f64,f64>");
+        else if (in_dtype == PIPE_HIP_F32)
+            PH_BQ(float, double, "biquad_kernel<f32,f64>");
+        else
+            PH_BQ(double, float, "biquad_kernel<f64,f32>");
+#undef PH_BQ
         PH_HIP(hipGetLastError());
         PH_TRY(timer.end(s));
         return PIPE_HIP_OK;
@@ -180,12 +200,23 @@ public:
 
 private:
     int S_ = 1;
+    bool has_gain_ = false;
+    double gain_ = 1.0;
     BiquadCoeffs q_{};
     DevBuf state_;
     size_t state_bytes_ = 0;
 };
 
 }  // namespace
+
+bool biquad_set_post_gain(pipe_hip_processor *p, bool on, double g)
+{
+    auto *b = dynamic_cast<Biquad *>(p);
+    if (!b)
+        return false;
+    b->set_post_gain(on, g);
+    return true;
+}
 
 int make_biquad(const pipe_hip_config *cfg, const double *coeffs, int32_t nsections,
                 pipe_hip_processor **out)

@@ -127,6 +127,9 @@ struct pipe_hip_processor {
     bool in_flight = false;
     int32_t in_flight_out_frames = 0;
     bool owned_by_chain = false;
+    // set by a chain for a stage whose float64 output feeds a chain that ends in float32:
+    // the stage may then use a form that is exact to O(1e-16) instead of bit-exact
+    bool relaxed_f64_out = false;
 
     virtual ~pipe_hip_processor();
 
@@ -194,5 +197,9 @@ int mix_run(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, v
             int64_t frames, hipStream_t s);
 
 int launch_synth_fill(void *d_out, int dtype, uint64_t seed, int64_t first, int64_t n, hipStream_t s);
+
+// chain fusion hooks: true when `p` is a gain stage (its current gain in *g) / a biquad stage
+bool gain_value(const pipe_hip_processor *p, double *g);
+bool biquad_set_post_gain(pipe_hip_processor *p, bool on, double g);
 
 }  // namespace pipehip

@@ -199,6 +199,15 @@ public:
 
 }  // namespace
 
+bool gain_value(const pipe_hip_processor *p, double *g)
+{
+    auto *q = dynamic_cast<const Gain *>(p);
+    if (!q)
+        return false;
+    *g = q->gain;
+    return true;
+}
+
 int make_gain(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out)
 {
     auto p = std::make_unique<Gain>();

@@ -454,7 +454,7 @@ public:
         // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
-        if (ols_ && !exact_ && out_dtype == PIPE_HIP_F32 &&
+        if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
             ols_->items(frames, cfg.channels, cfg.lines) >= ols_min_items()) {
             PH_TRY(timer.begin(s));
             PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, frames, cfg.channels, cfg.lines, s,

@@ -569,6 +569,19 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
             return launch_ols<double, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
+    // float64 output: only as an intermediate of a chain that ends in float32
+    if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
+        *kernel_name = "fir_ols_kernel<f32,f64>";
+        if (vec)
+            return launch_ols<float, double, 8, true>(*impl_, d_in, d_out, hist, a, s);
+        return launch_ols<float, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
+    }
+    if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
+        *kernel_name = "fir_ols_kernel<f64,f64>";
+        if (vec)
+            return launch_ols<double, double, 8, true>(*impl_, d_in, d_out, hist, a, s);
+        return launch_ols<double, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
+    }
     return PIPE_HIP_EINVAL;
 }
 

@@ -170,3 +170,36 @@ def test_ols_full_bench_size_against_bit_exact_form():
     assert max_ulp_big <= 1
     assert small_abs <= float(np.spacing(np.float32(floor)))
     assert n_diff / n < 1e-5
+
+
+def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    # BASELINE config[3] shape (many Lines x 8 ch, FIR + biquad + gain), large enough for the
+    # overlap-save FIR inside the chain; biquad+gain run as one pass.  Final float32 output is
+    # within 1 ulp of the oracle chain, and the exact-mode chain is bit-exact.
+    L_, F, C, N = 24, 4096, 8, 256
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    q = synth.biquad_rbj_lowpass()
+    g = 0.7071067811865476
+    x = np.stack([synth.samples(synth.line_seed(70 + l), 0, F * C, np.float32).reshape(F, C) for l in range(L_)])
+    floor = 2.0 ** -24 * np.abs(taps).sum()
+    for exact in (False, True):
+        kw = dict(dtype=np.float32, lines=L_, max_batch=1)
+        fir = P.Fir(taps, F, C, **kw)
+        if exact:
+            fir.set_exact(True)
+        with P.Chain([fir, P.Biquad(q, F, C, **kw), P.Gain(g, F, C, **kw)]) as p:
+            p.start()
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.empty_like(d_in)
+            p.process_batch(d_in, d_out, F)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            name = p.kernel_name()
+        assert ("fir_direct" in name) if exact else ("fir_ols" in name)
+        for l in (0, 7, 23):
+            want = O.gain(O.Biquad(q, C).process(O.Fir(taps, C).process(x[l].astype(np.float64))), g).reshape(F, C)
+            if exact:
+                assert np.array_equal(got[l], want.astype(np.float32))
+            else:
+                assert ulp_diff_f32(got[l], want, floor).max() <= 1.0
