@@ -12,6 +12,8 @@
 // is HBM/L2-bound, not ALU-bound.  An up-sampler emits more frames than it
 // consumes, which ProcessFunc cannot express with full buffers:
 // hence the explicit (in_frames, out_cap) -> out_frames ABI.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -56,6 +58,152 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs a
             acc = __builtin_fma(a.proto[p + (int64_t)j * a.up], v, acc);
         }
         out[((int64_t)line * a.out_cap + i) * a.C + c] = (TOut)acc;
+    }
+}
+
+// LDS-tiled form (used whenever the polyphase table fits): a workgroup owns kOutTile
+// consecutive output frames of one Line.  The table (tap-major: h[j*up + p], so lanes of
+// consecutive outputs -- phases 'down' apart -- hit distinct banks) and the input window
+// (per-channel float64 planes) are staged once; one lane = one output FRAME for all
+// channels, so every tap is read once per frame and the result leaves as one contiguous
+// C-element vector per lane (coalesced).  Same fma order as the gather kernel: bit-exact.
+constexpr int kOutTile = 1024;
+constexpr int kMaxCh = 8;
+
+struct TiledArgs {
+    ResampleArgs r;
+    int win;       // staged input frames per tile (upper bound)
+    int plane;     // plane stride (elements)
+    int cx_log;    // log2 of staging columns (pow2 >= C)
+    int tiles_per_line;
+};
+
+// CH channels of one output frame: acc[c] = fma(h[j], x_c[n-j], acc[c]), j ascending
+template <int CH, typename TOut>
+__device__ __forceinline__ void resample_taps(const double *__restrict__ hp, const double *__restrict__ xp,
+                                              int T, int up, int plane, TOut *__restrict__ o)
+{
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        acc[c] = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < T; ++j) {
+        const double hj = *hp;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            acc[c] = __builtin_fma(hj, xp[c * plane], acc[c]);
+        hp += up;
+        xp -= 1;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        o[c] = (TOut)acc[c];
+}
+
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArgs t)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ResampleArgs &a = t.r;
+    double *tab = reinterpret_cast<double *>(smem_raw);  // [T][up]
+    double *xs = tab + (size_t)a.T * a.up;                // [C][plane]
+    const int H = a.T - 1;
+    {   // proto is already [p + j*up]; staged once per (persistent) workgroup, 8 loads in flight
+        const int ntab = a.T * a.up;
+        for (int k0 = threadIdx.x; k0 < ntab; k0 += 8 * kThreads) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * kThreads;
+                v[u] = a.proto[k < ntab ? k : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * kThreads;
+                if (k < ntab)
+                    tab[k] = v[u];
+            }
+        }
+    }
+
+    const int ntiles = t.tiles_per_line * a.lines;
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+    const int line = tile_id / t.tiles_per_line;
+    const int tile = tile_id - line * t.tiles_per_line;
+    const int64_t m0 = a.out_total + (int64_t)tile * kOutTile;  // first output (global index)
+    const int64_t i0 = (int64_t)tile * kOutTile;                // ... relative to this call
+    const int nout = (int)min((int64_t)kOutTile, a.out_frames - i0);
+
+    // input frame (relative to this call's input) read by the tile's first output, minus history
+    const int64_t t0 = m0 * a.down;
+    const int64_t nfirst = t0 / a.up - a.in_total;
+    const unsigned r0 = (unsigned)(t0 % a.up);
+    const int64_t base = nfirst - H;  // frame of plane element 0
+    const TIn *__restrict__ in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * a.C;
+    const double *__restrict__ hist = a.hist + (int64_t)line * H * a.C;
+    {
+        const int tx = threadIdx.x & ((1 << t.cx_log) - 1);
+        const int ty = threadIdx.x >> t.cx_log;
+        const int FY = kThreads >> t.cx_log;
+        const bool ok = tx < a.C;
+        const int64_t last = a.in_frames - 1;
+        const TIn *__restrict__ src = in + (ok ? tx : 0);
+        for (int f0 = ty; f0 < t.win; f0 += 8 * FY) {
+            TIn v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int64_t g = base + f0 + u * FY;
+                g = g < 0 ? 0 : (g > last ? last : g);
+                v[u] = src[g * a.C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * FY;
+                const int64_t g = base + f;
+                const double loaded = (double)v[u];
+                if (ok && f < t.win) {
+                    double w = 0.0;
+                    if (g >= 0)
+                        w = g <= last ? loaded : 0.0;
+                    else if (g >= -(int64_t)H)
+                        w = hist[(g + H) * a.C + tx];
+                    xs[tx * t.plane + f] = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    TOut *__restrict__ out = reinterpret_cast<TOut *>(a.out) + ((int64_t)line * a.out_cap + i0) * a.C;
+    for (int ml = threadIdx.x; ml < nout; ml += kThreads) {
+        const unsigned tt = r0 + (unsigned)ml * (unsigned)a.down;  // < up + 1024*down: fits 32 bits
+        const unsigned nrel = tt / (unsigned)a.up;                 // input frame relative to nfirst
+        const unsigned p = tt - nrel * (unsigned)a.up;
+        const double *__restrict__ x = xs + nrel + H;  // element of frame (nfirst + nrel)
+        const double *__restrict__ h = tab + p;
+        // channels in compile-time groups of 8/4/2/1: the tap loop carries no predicates
+        int c0 = 0;
+        while (c0 < a.C) {
+            const int left = a.C - c0;
+            const double *__restrict__ xp = x + c0 * t.plane;
+            TOut *__restrict__ o = out + (int64_t)ml * a.C + c0;
+            if (left >= 8) {
+                resample_taps<8>(h, xp, a.T, a.up, t.plane, o);
+                c0 += 8;
+            } else if (left >= 4) {
+                resample_taps<4>(h, xp, a.T, a.up, t.plane, o);
+                c0 += 4;
+            } else if (left >= 2) {
+                resample_taps<2>(h, xp, a.T, a.up, t.plane, o);
+                c0 += 2;
+            } else {
+                resample_taps<1>(h, xp, a.T, a.up, t.plane, o);
+                c0 += 1;
+            }
+        }
+    }
+    __syncthreads();  // the planes are rewritten by the next tile
     }
 }
 
@@ -146,7 +294,42 @@ public:
         a.down = down_;
         a.lines = cfg.lines;
         const int64_t total = n_out * cfg.channels * cfg.lines;
-        if (total > 0) {
+        // staged window of a tile: frames read by kOutTile outputs, plus history, plus slack
+        const int win = (int)(((int64_t)kOutTile * down_ + up_ - 1) / up_) + T_ + 1;
+        int plane = win + 1;
+        plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
+        const size_t lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
+        const bool tiled = lds <= 64 * 1024 && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
+        if (total > 0 && tiled) {
+            TiledArgs t{};
+            t.r = a;
+            t.win = win;
+            t.plane = plane;
+            t.cx_log = 0;
+            while ((1 << t.cx_log) < cfg.channels)
+                ++t.cx_log;
+            t.tiles_per_line = (int)((n_out + kOutTile - 1) / kOutTile);
+            const int64_t ntiles = (int64_t)t.tiles_per_line * cfg.lines;
+            const int64_t slots = 3 * 256;  // ~3 workgroups per CU keep the table amortised
+            const int64_t per = (ntiles + slots - 1) / slots;
+            const dim3 grid((unsigned)((ntiles + per - 1) / per));
+            PH_TRY(timer.begin(s));
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+                hipLaunchKernelGGL((resample_tiled_kernel<float, float>), grid, dim3(kThreads), lds, s, t);
+                last_kernel = "resample_tiled_kernel<f32,f32>";
+            } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
+                hipLaunchKernelGGL((resample_tiled_kernel<double, double>), grid, dim3(kThreads), lds, s, t);
+                last_kernel = "resample_tiled_kernel<f64,f64>";
+            } else if (in_dtype == PIPE_HIP_F32) {
+                hipLaunchKernelGGL((resample_tiled_kernel<float, double>), grid, dim3(kThreads), lds, s, t);
+                last_kernel = "resample_tiled_kernel<f32,f64>";
+            } else {
+                hipLaunchKernelGGL((resample_tiled_kernel<double, float>), grid, dim3(kThreads), lds, s, t);
+                last_kernel = "resample_tiled_kernel<f64,f32>";
+            }
+            PH_HIP(hipGetLastError());
+            PH_TRY(timer.end(s));
+        } else if (total > 0) {
             int64_t b = (total + kThreads - 1) / kThreads;
             if (b > 4096)
                 b = 4096;
