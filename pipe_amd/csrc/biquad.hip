@@ -22,7 +22,7 @@ namespace {
 
 constexpr int kMaxSections = 8;
 constexpr int kThreads = 64;
-constexpr int kChunk = 16;  // frames in flight per lane
+constexpr int kChunk = 32;  // frames per chunk; two chunks in flight per lane
 
 struct BiquadCoeffs {
     double c[kMaxSections][5];
@@ -100,19 +100,40 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
 
     const int64_t stride = a.C;
     int64_t f = 0;
-    for (; f + kChunk <= a.frames; f += kChunk) {
-        TIn x[kChunk];
+    // two chunks in flight: chunk k+1 is loading while the dependent chain walks chunk k
+    // (series are scarce -- 64 waves for 4096 series -- so no other wave hides the latency)
+    const int64_t nchunks = a.frames / kChunk;
+    TIn xa[kChunk], xb[kChunk];
+    if (nchunks > 0) {
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
-            x[u] = in[(f + u) * stride];
+            xa[u] = in[u * stride];
+    }
+    auto run_chunk = [&](const TIn (&x)[kChunk], int64_t f0) {
         TOut y[kChunk];
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
             y[u] = (TOut)step((double)x[u]);
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
-            out[(f + u) * stride] = y[u];
+            out[(f0 + u) * stride] = y[u];
+    };
+    int64_t k = 0;
+    for (; k + 2 <= nchunks; k += 2) {
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+            xb[u] = in[((k + 1) * kChunk + u) * stride];
+        run_chunk(xa, k * kChunk);
+        if (k + 2 < nchunks) {
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u)
+                xa[u] = in[((k + 2) * kChunk + u) * stride];
+        }
+        run_chunk(xb, (k + 1) * kChunk);
     }
+    if (k < nchunks)
+        run_chunk(xa, k * kChunk);
+    f = nchunks * kChunk;
     for (; f < a.frames; ++f)
         out[f * stride] = (TOut)step((double)in[f * stride]);
 

@@ -36,16 +36,6 @@ def expect(y64, dtype):
     return np.asarray(y64, dtype=np.float64).astype(dtype)
 
 
-def ragged(total, pieces):
-    cuts = [0] + list(pieces)
-    acc, out = 0, []
-    for p in pieces:
-        out.append((acc, min(acc + p, total)))
-        acc += p
-    assert acc >= total
-    return [(a, b) for a, b in out if a < total or a == b]
-
-
 # ------------------------------------------------------------------ copy / gain
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("data", [[1, 1, 1, 1], [1, 1, 1, 1, 2, 2, 2, 2]])
