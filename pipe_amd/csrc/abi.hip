@@ -2,6 +2,8 @@
 // handle that every Processor kind shares: device selection, the handle's stream,
 // pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
 // bracket used for live kernel timing.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -140,6 +142,12 @@ int pipe_hip_processor::ensure_staging()
     PH_TRY(d_out.alloc(out_b));
     PH_TRY(h_in.alloc(in_b));
     PH_TRY(h_out.alloc(out_b));
+    // device-side aliases of the pinned buffers (zero-copy path of small buffers)
+    if (hipHostGetDevicePointer(&hd_in, h_in.p, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&hd_out, h_out.p, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        hd_in = hd_out = nullptr;
+    }
     return PIPE_HIP_OK;
 }
 
@@ -176,16 +184,31 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     } else if (out_cap_hint >= 0 && in_frames > out_cap_hint) {
         return PIPE_HIP_ECAP;
     }
-    if (in_b) {
+    // One pipe buffer is tens of KiB: two DMA launches cost more than the transfer.  Small
+    // buffers are therefore processed zero-copy -- the kernels read the pinned staging
+    // buffer and write the pinned result buffer straight over PCIe (one launch chain, no
+    // hipMemcpyAsync); large ones (many Lines per handle) keep the DMA engines.
+    static const size_t zero_copy_max = [] {
+        const char *e = std::getenv("PIPE_HIP_ZERO_COPY_MAX");
+        return e ? (size_t)std::atoll(e) : (size_t)(1u << 20);
+    }();
+    const size_t out_b_cap = es * (size_t)p->cfg.lines * (size_t)cap * (size_t)p->out_channels();
+    const bool zero_copy = in_b <= zero_copy_max && out_b_cap <= zero_copy_max && p->hd_in && p->hd_out;
+    if (in_b)
         std::memcpy(p->h_in.p, in, in_b);
-        PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
+    if (zero_copy) {
+        PH_TRY(p->run_var(p->hd_in, p->cfg.dtype, in_frames, p->hd_out, p->cfg.dtype, cap, &out_frames,
+                          p->stream));
+    } else {
+        if (in_b)
+            PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
+        PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, in_frames, p->d_out.p, p->cfg.dtype, cap, &out_frames,
+                          p->stream));
+        const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
+                             (size_t)p->out_channels();
+        if (out_b)
+            PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
     }
-    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, in_frames, p->d_out.p, p->cfg.dtype, cap, &out_frames,
-                      p->stream));
-    const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
-                         (size_t)p->out_channels();
-    if (out_b)
-        PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
     PH_HIP(hipEventRecord(p->done, p->stream));
     p->in_flight = true;
     p->in_flight_out_frames = (int32_t)out_frames;

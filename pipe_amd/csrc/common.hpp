@@ -123,6 +123,7 @@ struct pipe_hip_processor {
     // host<->device staging for the ProcessFunc form (lazily sized)
     pipehip::DevBuf d_in, d_out;
     pipehip::PinnedBuf h_in, h_out;
+    void *hd_in = nullptr, *hd_out = nullptr;  // device aliases of h_in / h_out (zero-copy path)
     hipEvent_t done = nullptr;
     bool in_flight = false;
     int32_t in_flight_out_frames = 0;

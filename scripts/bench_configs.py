@@ -50,6 +50,22 @@ def config0():
 def config1_per_call():
     F, C, N = 4096, 2, 256
     taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    # through the compiled host mirror (no Python in the loop): mock.Source -> HIP FIR -> mock.Sink.
+    # bind + handle creation are paid once per run, so time two stream lengths and difference them
+    for mode, mname in ((H.MODE_RUN, "pipe.Run"), (H.MODE_ASYNC, "pipe.New+Start")):
+        def run_n(n):
+            line = H.Line(limit=n * F, channels=C, value=0.25, discard=True, procs=[H.Proc(H.PROC_HIP_FIR, taps)])
+            t0 = time.perf_counter()
+            err, res = H.run(F, [line], mode)
+            dt = time.perf_counter() - t0
+            assert not err.failed and res[0].sink.messages == n
+            return dt
+        run_n(50)
+        t_small, t_big = run_n(500), run_n(4500)
+        per = (t_big - t_small) / 4000
+        emit(config=1, what="C++ host mirror: mock.Source -> HIP FIR-256 (f64 buffers, ProcessFunc per buffer) -> mock.Sink, 4096x2",
+             mode=mname, us_per_buffer=round(per * 1e6, 2), setup_ms=round((t_small - 500 * per) * 1e3, 2),
+             msamples_per_s=round(F * C / per / 1e6, 2), realtime_factor_48k=round(F / 48000 / per, 1))
     x = synth.samples(synth.line_seed(0), 0, F * C, np.float32).reshape(F, C)
     for dtype in (np.float32, np.float64):
         with P.Fir(taps, F, C, dtype=dtype) as p:
