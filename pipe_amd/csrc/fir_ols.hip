@@ -249,10 +249,12 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     };
     auto decode = [&](int64_t item) {
         Item it;
-        const int tile = (int)(item % a.tiles_per_line);
-        const int64_t rest = item / a.tiles_per_line;
-        const int pair = (int)(rest % a.pairs);
-        it.line = (int)(rest / a.pairs);
+        // channel pair fastest: the pairs of one tile read the same cache lines, and
+        // neighbouring waves of a workgroup work on them at the same time
+        const int pair = (int)(item % a.pairs);
+        const int64_t rest = item / a.pairs;
+        const int tile = (int)(rest % a.tiles_per_line);
+        it.line = (int)(rest / a.tiles_per_line);
         it.c0 = pair * 2;
         it.two = it.c0 + 1 < a.C;
         it.t0 = (int64_t)tile * a.L;
