@@ -32,8 +32,8 @@ struct BiquadArgs {
     double *state;  // [lines][C][S][2]
     int64_t frames;
     int C, S, nseries;
-    int has_gain;
     double gain;
+    int64_t in_bytes, out_bytes;  // extent of the call's buffers (< 4 GiB)
 };
 
 template <int NS>
@@ -52,27 +52,60 @@ __device__ __forceinline__ double biquad_step(double x, double (&s1)[kMaxSection
     return x;
 }
 
-// NS = compile-time section count (1, 2) or 0 = runtime a.S
-template <typename TIn, typename TOut, int NS>
+// Element access through a buffer resource: the per-lane part of the address (which
+// series) is a 32-bit VGPR offset computed once, the per-frame part is a wave-uniform SGPR
+// offset -- so the dependent fma chain shares the lane's single VALU issue slot (one
+// instruction per ~4.4 cycles for a lone wave) with no address arithmetic at all.
+template <typename T>
+__device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ float buf_load<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <>
+__device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
+}
+
+// NS = compile-time section count (1, 2) or 0 = runtime a.S; GAIN = a gain is folded in
+template <typename TIn, typename TOut, int NS, bool GAIN>
 __global__ void __launch_bounds__(kThreads)
 biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a,
               const BiquadCoeffs q)
 {
     const int sid = blockIdx.x * kThreads + threadIdx.x;
-    if (sid >= a.nseries)
-        return;
-    const int line = sid / a.C;
-    const int c = sid - line * a.C;
-    const TIn *__restrict__ in = in_base + (int64_t)line * a.frames * a.C + c;
-    TOut *__restrict__ out = out_base + (int64_t)line * a.frames * a.C + c;
-    double *__restrict__ st = a.state + (int64_t)sid * a.S * 2;
+    const bool live = sid < a.nseries;
+    const int sidc = live ? sid : 0;
+    const int line = sidc / a.C;
+    const int c = sidc - line * a.C;
+    double *__restrict__ st = a.state + (int64_t)sidc * a.S * 2;
+    // whole call through 32-bit offsets (the launcher guarantees the buffers are < 4 GiB)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TIn *>(in_base), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, (int)a.out_bytes, 0x00020000);
+    // dead lanes point past the end: their loads return 0 and their stores are dropped
+    const unsigned vin = live ? (unsigned)(((int64_t)line * a.frames * a.C + c) * sizeof(TIn)) : 0xFFFFFFFFu;
+    const unsigned vout = live ? (unsigned)(((int64_t)line * a.frames * a.C + c) * sizeof(TOut)) : 0xFFFFFFFFu;
+    const unsigned sin_step = (unsigned)(a.C * sizeof(TIn));    // bytes per frame
+    const unsigned sout_step = (unsigned)(a.C * sizeof(TOut));
 
     double s1[kMaxSections], s2[kMaxSections];
 #pragma unroll
     for (int s = 0; s < kMaxSections; ++s) {
         s1[s] = 0.0;
         s2[s] = 0.0;
-        if (s < a.S) {
+        if (live && s < a.S) {
             s1[s] = st[2 * s];
             s2[s] = st[2 * s + 1];
         }
@@ -95,11 +128,11 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
                 }
             }
         }
-        return a.has_gain ? y * a.gain : y;
+        if constexpr (GAIN)
+            y = y * a.gain;
+        return y;
     };
 
-    const int64_t stride = a.C;
-    int64_t f = 0;
     // two chunks in flight: chunk k+1 is loading while the dependent chain walks chunk k
     // (series are scarce -- 64 waves for 4096 series -- so no other wave hides the latency)
     const int64_t nchunks = a.frames / kChunk;
@@ -107,41 +140,47 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
     if (nchunks > 0) {
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
-            xa[u] = in[u * stride];
+            xa[u] = buf_load<TIn>(rin, vin, (unsigned)u * sin_step);
     }
     auto run_chunk = [&](const TIn (&x)[kChunk], int64_t f0) {
         TOut y[kChunk];
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
             y[u] = (TOut)step((double)x[u]);
+        const unsigned so = (unsigned)f0 * sout_step;
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
-            out[(f0 + u) * stride] = y[u];
+            buf_store(rout, vout, so + (unsigned)u * sout_step, y[u]);
     };
     int64_t k = 0;
     for (; k + 2 <= nchunks; k += 2) {
+        const unsigned sb = (unsigned)((k + 1) * kChunk) * sin_step;
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
-            xb[u] = in[((k + 1) * kChunk + u) * stride];
+            xb[u] = buf_load<TIn>(rin, vin, sb + (unsigned)u * sin_step);
         run_chunk(xa, k * kChunk);
         if (k + 2 < nchunks) {
+            const unsigned sa = (unsigned)((k + 2) * kChunk) * sin_step;
 #pragma unroll
             for (int u = 0; u < kChunk; ++u)
-                xa[u] = in[((k + 2) * kChunk + u) * stride];
+                xa[u] = buf_load<TIn>(rin, vin, sa + (unsigned)u * sin_step);
         }
         run_chunk(xb, (k + 1) * kChunk);
     }
     if (k < nchunks)
         run_chunk(xa, k * kChunk);
-    f = nchunks * kChunk;
-    for (; f < a.frames; ++f)
-        out[f * stride] = (TOut)step((double)in[f * stride]);
+    for (int64_t f = nchunks * kChunk; f < a.frames; ++f) {
+        const double y = step((double)buf_load<TIn>(rin, vin, (unsigned)f * sin_step));
+        buf_store(rout, vout, (unsigned)f * sout_step, (TOut)y);
+    }
 
+    if (live) {
 #pragma unroll
-    for (int s = 0; s < kMaxSections; ++s) {
-        if (s < a.S) {
-            st[2 * s] = s1[s];
-            st[2 * s + 1] = s2[s];
+        for (int s = 0; s < kMaxSections; ++s) {
+            if (s < a.S) {
+                st[2 * s] = s1[s];
+                st[2 * s + 1] = s2[s];
+            }
         }
     }
 }
@@ -188,21 +227,31 @@ public:
         a.C = cfg.channels;
         a.S = S_;
         a.nseries = cfg.lines * cfg.channels;
-        a.has_gain = has_gain_ ? 1 : 0;
         a.gain = gain_;
+        a.in_bytes = (int64_t)dtype_size(in_dtype) * frames * cfg.channels * cfg.lines;
+        a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * cfg.lines;
+        if (a.in_bytes >= ((int64_t)1 << 32) - 4096 || a.out_bytes >= ((int64_t)1 << 32) - 4096)
+            return PIPE_HIP_EINVAL;  // 32-bit buffer offsets: split the call (never reached by buffer_size*max_batch in practice)
         const dim3 grid((unsigned)((a.nseries + kThreads - 1) / kThreads));
         PH_TRY(timer.begin(s));
-#define PH_BQ(TI, TO, NAME)                                                                         \
+#define PH_BQ2(TI, TO, G)                                                                           \
     do {                                                                                            \
         if (S_ == 1)                                                                                \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 1>), grid, dim3(kThreads), 0, s,              \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 1, G>), grid, dim3(kThreads), 0, s,           \
                                static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
         else if (S_ == 2)                                                                           \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 2>), grid, dim3(kThreads), 0, s,              \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 2, G>), grid, dim3(kThreads), 0, s,           \
                                static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
         else                                                                                        \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 0>), grid, dim3(kThreads), 0, s,              \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 0, G>), grid, dim3(kThreads), 0, s,           \
                                static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
+    } while (0)
+#define PH_BQ(TI, TO, NAME)                                                                         \
+    do {                                                                                            \
+        if (has_gain_)                                                                              \
+            PH_BQ2(TI, TO, true);                                                                   \
+        else                                                                                        \
+            PH_BQ2(TI, TO, false);                                                                  \
         last_kernel = NAME;                                                                         \
     } while (0)
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
@@ -214,6 +263,7 @@ public:
         else
             PH_BQ(double, float, "biquad_kernel<f64,f32>");
 #undef PH_BQ
+#undef PH_BQ2
         PH_HIP(hipGetLastError());
         PH_TRY(timer.end(s));
         return PIPE_HIP_OK;
