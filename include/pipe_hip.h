@@ -121,6 +121,15 @@ int pipe_hip_destroy(pipe_hip_processor *p);
  * the pipe (pipe.go:431).  in and out must not alias. */
 int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, void *out,
                      int32_t out_cap_frames, int32_t *out_frames);
+/* One step of MANY Lines through one handle (cfg.lines = L): the batched form of the
+ * multiLineExecutor pass (run.go:112-132), which calls ProcessFunc once per Line.  ins[l] /
+ * outs[l] are the HOST buffers of Line l (its own pool buffers, not contiguous with the
+ * others); in_frames[l] <= buffer_size may differ per Line (short last buffers): shorter
+ * Lines are zero-padded on the device and only their own frames are written back, a NULL
+ * ins[l] is a Line that has ended.  out_frames[l] (optional) receives in_frames[l].
+ * Fixed-rate processors only.  Synchronous. */
+int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
+                           void *const *outs, int32_t *out_frames);
 /* ProcessFunc for the n-input mix: ins[i] are HOST pointers of `frames` frames. */
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
                          int32_t frames, void *out);

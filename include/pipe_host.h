@@ -28,7 +28,12 @@ enum { /* processor kinds */
     PIPE_HOST_PROC_HIP_CHAIN = 5   /* params = {ntaps, taps..., nsections, coeffs..., gain} fused on device */
 };
 enum { PIPE_HOST_SRC_CONST = 0, PIPE_HOST_SRC_SYNTH = 1, PIPE_HOST_SRC_ARRAY = 2 };
-enum { PIPE_HOST_MODE_RUN = 0 /* pipe.Run */, PIPE_HOST_MODE_ASYNC = 1 /* pipe.New + Start + Wait */ };
+enum {
+    PIPE_HOST_MODE_RUN = 0,        /* pipe.Run */
+    PIPE_HOST_MODE_ASYNC = 1,      /* pipe.New + Start + Wait */
+    PIPE_HOST_MODE_RUN_BATCHED = 2 /* stage-major Run: a HIP_CHAIN with identical parameters at the same
+                                      position of every Line advances with ONE launch per pass */
+};
 
 typedef struct pipe_host_proc_desc {
     int32_t kind;

@@ -402,6 +402,54 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
     return collect_impl(p, out, out_cap_frames, out_frames);
 }
 
+int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
+                           void *const *outs, int32_t *out_frames)
+{
+    if (!p || !ins || !in_frames || !outs || !p->fixed_rate() || !p->single_input())
+        return PIPE_HIP_EINVAL;
+    if (p->in_flight)
+        return PIPE_HIP_ESTATE;
+    PH_TRY(p->select_device());
+    PH_TRY(p->ensure_staging());
+    const int L = p->cfg.lines;
+    int32_t frames = 0;
+    for (int l = 0; l < L; ++l) {
+        if (in_frames[l] < 0 || in_frames[l] > p->cfg.buffer_size || (ins[l] && in_frames[l] > 0 && !outs[l]))
+            return PIPE_HIP_EINVAL;
+        if (ins[l] && in_frames[l] > frames)
+            frames = in_frames[l];
+    }
+    if (out_frames)
+        for (int l = 0; l < L; ++l)
+            out_frames[l] = ins[l] ? in_frames[l] : 0;
+    if (frames == 0)
+        return PIPE_HIP_OK;
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t row_in = es * (size_t)frames * (size_t)p->cfg.channels;
+    const size_t row_out = es * (size_t)frames * (size_t)p->out_channels();
+    // gather: Line l occupies [l][frames][channels] of the pinned staging buffer
+    for (int l = 0; l < L; ++l) {
+        char *dst = static_cast<char *>(p->h_in.p) + row_in * l;
+        const size_t have = ins[l] ? es * (size_t)in_frames[l] * (size_t)p->cfg.channels : 0;
+        if (have)
+            std::memcpy(dst, ins[l], have);
+        if (have < row_in)
+            std::memset(dst + have, 0, row_in - have);
+    }
+    int64_t produced = frames;
+    PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, row_in * L, hipMemcpyHostToDevice, p->stream));
+    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, frames, p->d_out.p, p->cfg.dtype, frames, &produced, p->stream));
+    PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, row_out * L, hipMemcpyDeviceToHost, p->stream));
+    PH_HIP(hipStreamSynchronize(p->stream));
+    for (int l = 0; l < L; ++l) {
+        if (!ins[l] || in_frames[l] == 0)
+            continue;
+        std::memcpy(outs[l], static_cast<const char *>(p->h_out.p) + row_out * l,
+                    es * (size_t)in_frames[l] * (size_t)p->out_channels());
+    }
+    return PIPE_HIP_OK;
+}
+
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
                          int32_t frames, void *out)
 {

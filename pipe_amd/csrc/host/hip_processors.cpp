@@ -124,10 +124,11 @@ ProcessorAllocatorFunc Biquad(std::vector<double> coeffs, Options o, std::shared
     };
 }
 
-ProcessorAllocatorFunc Chain(std::vector<StageSpec> stages, Options o, std::shared_ptr<Handle> *handle)
+namespace {
+
+error build_chain(const std::vector<StageSpec> &stages, const pipe_hip_config &c, pipe_hip_processor **chain_out)
 {
-    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
-        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+    {
         std::vector<pipe_hip_processor *> raws;
         auto cleanup = [&raws]() {
             for (auto *r : raws)
@@ -154,8 +155,114 @@ ProcessorAllocatorFunc Chain(std::vector<StageSpec> stages, Options o, std::shar
             cleanup();
             return StatusError(st, "chain_create");
         }
+        *chain_out = chain;
+        return nullptr;
+    }
+}
+
+// one handle shared by the Processors of `lines` Lines
+class HipBatch final : public BatchGroup {
+public:
+    HipBatch(std::vector<StageSpec> stages, int lines, Options o) : stages_(std::move(stages)), lines_(lines), o_(o) {}
+    int Slots() const override { return lines_; }
+
+    // first allocator call creates the handle; the others must agree on the geometry
+    error bind(int bufferSize, const SignalProperties &input, std::shared_ptr<Handle> *handle)
+    {
+        if (h_) {
+            if (bufferSize != bufferSize_ || input.Channels != channels_)
+                return NewError("batched chain: every Line must have the same buffer size and channels");
+            return nullptr;
+        }
+        pipe_hip_config c = make_cfg(o_, bufferSize, input);
+        c.lines = lines_;
+        pipe_hip_processor *raw = nullptr;
+        if (error e = build_chain(stages_, c, &raw))
+            return e;
+        h_ = std::make_shared<Handle>(raw);
+        if (handle)
+            *handle = h_;
+        bufferSize_ = bufferSize;
+        channels_ = input.Channels;
+        return nullptr;
+    }
+    const std::shared_ptr<Handle> &handle() const { return h_; }
+
+    // every slot's StartFunc lands here (all of them run before the first pass: run.go:76-85)
+    error start() { return StatusError(pipe_hip_start(h_->get()), "start"); }
+
+    error ProcessLines(const std::vector<const signal::Floating *> &ins, const std::vector<signal::Floating *> &outs,
+                       std::vector<int> *processed) override
+    {
+        const size_t n = (size_t)lines_;
+        in_ptr_.assign(n, nullptr);
+        out_ptr_.assign(n, nullptr);
+        frames_.assign(n, 0);
+        written_.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            if (!ins[i])
+                continue;
+            if (outs[i]->Length() < ins[i]->Length())
+                return NewError("batched chain: output buffer shorter than input");
+            in_ptr_[i] = ins[i]->data();
+            out_ptr_[i] = outs[i]->data();
+            frames_[i] = ins[i]->Length();
+        }
+        const int st = pipe_hip_process_lines(h_->get(), in_ptr_.data(), frames_.data(), out_ptr_.data(), written_.data());
+        if (st != PIPE_HIP_OK)
+            return StatusError(st, "process_lines");
+        for (size_t i = 0; i < n; ++i)
+            (*processed)[i] = written_[i];
+        return nullptr;
+    }
+
+private:
+    std::vector<StageSpec> stages_;
+    int lines_;
+    Options o_;
+    std::shared_ptr<Handle> h_;
+    int bufferSize_ = 0, channels_ = 0;
+    std::vector<const void *> in_ptr_;
+    std::vector<void *> out_ptr_;
+    std::vector<int32_t> frames_, written_;
+};
+
+}  // namespace
+
+ProcessorAllocatorFunc Chain(std::vector<StageSpec> stages, Options o, std::shared_ptr<Handle> *handle)
+{
+    return [=](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+        const pipe_hip_config c = make_cfg(o, bufferSize, input);
+        pipe_hip_processor *chain = nullptr;
+        if (error e = build_chain(stages, c, &chain))
+            return e;
         return finish(chain, input, out, handle);
     };
+}
+
+std::vector<ProcessorAllocatorFunc> BatchedChain(std::vector<StageSpec> stages, int lines, Options o,
+                                                 std::shared_ptr<Handle> *handle)
+{
+    auto group = std::make_shared<HipBatch>(std::move(stages), lines, o);
+    std::vector<ProcessorAllocatorFunc> allocs;
+    for (int slot = 0; slot < lines; ++slot) {
+        allocs.push_back([group, slot, handle](mut::Context, int bufferSize, SignalProperties input, Processor *out) -> error {
+            if (error e = group->bind(bufferSize, input, handle))
+                return e;
+            out->SignalProperties = input;  // a chain keeps rate and channels
+            out->Batch = group;
+            out->BatchSlot = slot;
+            out->StartFunc = [group](const Context &) -> error { return group->start(); };
+            out->FlushFunc = [group](const Context &) -> error {
+                return StatusError(pipe_hip_flush(group->handle()->get()), "flush");
+            };
+            out->ProcessFunc = [](const signal::Floating &, signal::Floating &, int *) -> error {
+                return NewError("batched processor: run the Lines with pipe::RunBatched");
+            };
+            return nullptr;
+        });
+    }
+    return allocs;
 }
 
 }  // namespace hip

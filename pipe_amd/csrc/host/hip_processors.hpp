@@ -56,6 +56,13 @@ struct StageSpec {
 ProcessorAllocatorFunc Chain(std::vector<StageSpec> stages, Options o = {},
                              std::shared_ptr<Handle> *handle = nullptr);
 
+// The same chain for `lines` Lines behind ONE device handle (cfg.lines = lines): element i of
+// the result is the allocator for Line i.  The Processors it makes only run under
+// pipe::RunBatched, where all of them advance with one pipe_hip_process_lines call per pass;
+// their parameters are shared (a mutation queued on *handle changes every Line of the group).
+std::vector<ProcessorAllocatorFunc> BatchedChain(std::vector<StageSpec> stages, int lines, Options o = {},
+                                                 std::shared_ptr<Handle> *handle = nullptr);
+
 // route pool buffers through pinned memory (called once when a device exists)
 void UsePinnedPools();
 

@@ -89,6 +89,47 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
     bool any_hip = false;
     hip::Options opt;
     opt.device = device;
+    // {ntaps, taps..., nsections, coeffs..., gain}
+    auto parse_chain = [](const std::vector<double> &params, std::vector<hip::StageSpec> *st) -> bool {
+        size_t p = 0;
+        if (params.size() < 3)
+            return false;
+        const size_t nt = (size_t)params[p++];
+        if (p + nt + 1 > params.size())
+            return false;
+        st->push_back({hip::StageSpec::kFir, std::vector<double>(params.begin() + (long)p, params.begin() + (long)(p + nt))});
+        p += nt;
+        const size_t ns = (size_t)params[p++];
+        if (p + 5 * ns + 1 > params.size())
+            return false;
+        st->push_back({hip::StageSpec::kBiquad,
+                       std::vector<double>(params.begin() + (long)p, params.begin() + (long)(p + 5 * ns))});
+        p += 5 * ns;
+        st->push_back({hip::StageSpec::kGain, {params[p]}});
+        return true;
+    };
+    // batched mode: a HIP chain with identical parameters at position k of EVERY Line becomes
+    // one BatchGroup (one device handle, one launch per pass)
+    std::vector<std::vector<ProcessorAllocatorFunc>> batched((size_t)PIPE_HOST_MAX_PROCS);
+    std::vector<std::shared_ptr<hip::Handle>> batch_handles((size_t)PIPE_HOST_MAX_PROCS);
+    if (mode == PIPE_HOST_MODE_RUN_BATCHED) {
+        for (int k = 0; k < descs[0].n_procs && k < PIPE_HOST_MAX_PROCS; ++k) {
+            bool same = true;
+            for (int i = 0; i < n_lines && same; ++i) {
+                const pipe_host_proc_desc &a = descs[0].procs[k];
+                same = descs[i].n_procs > k && descs[i].procs[k].kind == PIPE_HOST_PROC_HIP_CHAIN &&
+                       descs[i].procs[k].n_params == a.n_params && descs[i].procs[k].params &&
+                       std::memcmp(descs[i].procs[k].params, a.params, sizeof(double) * (size_t)a.n_params) == 0;
+            }
+            if (!same)
+                continue;
+            std::vector<hip::StageSpec> st;
+            const pipe_host_proc_desc &a = descs[0].procs[k];
+            if (!parse_chain(std::vector<double>(a.params, a.params + a.n_params), &st))
+                return 1;
+            batched[(size_t)k] = hip::BatchedChain(st, n_lines, opt, &batch_handles[(size_t)k]);
+        }
+    }
     for (int i = 0; i < n_lines; ++i) {
         const pipe_host_line_desc &d = descs[i];
         auto m = std::make_unique<LineMocks>();
@@ -148,21 +189,15 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
                 any_hip = true;
                 break;
             case PIPE_HOST_PROC_HIP_CHAIN: {
-                // {ntaps, taps..., nsections, coeffs..., gain}
-                std::vector<hip::StageSpec> st;
-                size_t p = 0;
-                if (params.size() < 3)
-                    return 1;
-                const size_t nt = (size_t)params[p++];
-                st.push_back({hip::StageSpec::kFir, std::vector<double>(params.begin() + (long)p, params.begin() + (long)(p + nt))});
-                p += nt;
-                const size_t ns = (size_t)params[p++];
-                st.push_back({hip::StageSpec::kBiquad,
-                              std::vector<double>(params.begin() + (long)p, params.begin() + (long)(p + 5 * ns))});
-                p += 5 * ns;
-                st.push_back({hip::StageSpec::kGain, {params[p]}});
-                l.Processors.push_back(counted(hip::Chain(st, opt, hslot), pm.get()));
                 any_hip = true;
+                if (!batched[(size_t)k].empty()) {
+                    l.Processors.push_back(batched[(size_t)k][(size_t)i]);
+                    break;
+                }
+                std::vector<hip::StageSpec> st;
+                if (!parse_chain(params, &st))
+                    return 1;
+                l.Processors.push_back(counted(hip::Chain(st, opt, hslot), pm.get()));
                 break;
             }
             default:
@@ -179,12 +214,12 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
     error run_err;
     bool bind_err = false;
     const Context ctx = Context::Background();
-    if (mode == PIPE_HOST_MODE_RUN) {
+    if (mode == PIPE_HOST_MODE_RUN || mode == PIPE_HOST_MODE_RUN_BATCHED) {
         for (int r = 0; r < (runs < 1 ? 1 : runs) && !run_err; ++r) {
             if (r > 0)
                 for (auto &m : mocks)
                     m->source.Reset().Apply();
-            run_err = Run(ctx, buffer_size, lines);
+            run_err = mode == PIPE_HOST_MODE_RUN ? Run(ctx, buffer_size, lines) : RunBatched(ctx, buffer_size, lines);
         }
     } else {
         std::unique_ptr<Pipe> p;

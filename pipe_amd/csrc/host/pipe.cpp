@@ -3,6 +3,7 @@
 // Citations are into /root/reference.
 #include "pipe.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <random>
 #include <stdexcept>
@@ -316,6 +317,44 @@ error Processor::execute(const ::pipe::Context &ctx)
     return nullptr;
 }
 
+error Processor::batchBegin(const ::pipe::Context &ctx, Pending *pd)
+{
+    bool ok = false;
+    pd->m = in.receiver->Receive(ctx, &ok);
+    if (!ok) {
+        out.sender->Close();
+        return io::EOF_();
+    }
+    if (error e = pd->m.Mutations.ApplyTo(Context)) {
+        pd->m.Signal.Free(in.allocator.get());
+        return e;
+    }
+    pd->output = out.allocator->Float64();
+    return nullptr;
+}
+
+error Processor::batchEnd(const ::pipe::Context &ctx, Pending &pd, int processed, const error &procErr)
+{
+    struct Defer {
+        signal::Floating &s;
+        signal::PoolAllocator *p;
+        ~Defer() { s.Free(p); }
+    } free_input{pd.m.Signal, in.allocator.get()};
+    if (procErr) {
+        out.sender->Close();
+        return procErr;
+    }
+    signal::Floating output = pd.output;
+    if (processed != out.allocator->Length)
+        output = output.Slice(0, processed);
+    if (!out.sender->Send(ctx, fitting::Message{output, pd.m.Mutations})) {
+        out.sender->Close();
+        output.Free(out.allocator.get());
+        return io::EOF_();
+    }
+    return nullptr;
+}
+
 error Processor::startHook(const ::pipe::Context &ctx) { return callHook(StartFunc, ctx); }
 error Processor::flushHook(const ::pipe::Context &ctx) { return callHook(FlushFunc, ctx); }
 
@@ -520,6 +559,175 @@ struct multiLineExecutor final : executor {
     }
 };
 
+// stageMajorExecutor: the multiLineExecutor pass turned inside out (stage-major instead of
+// Line-major) so that the Processors of a BatchGroup meet in one call.  Start / flush / EOF
+// removal follow multiLineExecutor (run.go:76-132).
+struct stageMajorExecutor final : executor {
+    struct entry {
+        std::shared_ptr<route> r;
+        std::shared_ptr<lineExecutor> le;
+    };
+    std::vector<entry> lines;
+
+    error flushHook(const Context &ctx) override
+    {
+        std::vector<error> errs;
+        for (auto &l : lines)
+            if (error e = l.le->flushHook(ctx))
+                errs.push_back(e);
+        return joinErrors(errs);
+    }
+    error startHook(const Context &ctx) override
+    {
+        error startErr;
+        for (auto &l : lines) {
+            if (error e = l.le->startHook(ctx)) {
+                startErr = e;
+                break;
+            }
+        }
+        if (!startErr)
+            return nullptr;
+        error err = Wrap("error starting lines", startErr);
+        if (error flushErr = flushHook(ctx)) {
+            auto v = std::make_shared<ErrorValue>();
+            v->msg = "error flushing lines: " + ErrorString(flushErr) + " during start error: " + ErrorString(err);
+            v->cause = flushErr;
+            return v;
+        }
+        return err;
+    }
+
+    // Line i hit EOF before stage `from`: let the EOF travel through its remaining stages
+    // (run.go:44-46), flush it and drop it (run.go:120-128).
+    error retire(const Context &ctx, size_t i, size_t from)
+    {
+        entry &l = lines[i];
+        for (size_t p = from; p < l.r->processors.size(); ++p) {
+            error e = l.r->processors[p]->execute(ctx);
+            if (e && e != io::EOF_())
+                return e;
+        }
+        if (from <= l.r->processors.size()) {
+            error e = l.r->sink->execute(ctx);
+            if (e && e != io::EOF_())
+                return e;
+        }
+        if (error flushErr = l.le->flushHook(ctx))
+            return flushErr;
+        lines.erase(lines.begin() + (long)i);
+        return nullptr;
+    }
+
+    struct pending {
+        Processor *proc;
+        Processor::Pending pd;
+    };
+
+    error execute(const Context &ctx) override
+    {
+        for (size_t i = 0; i < lines.size();) {
+            error err = lines[i].r->source->execute(ctx);
+            if (!err) {
+                ++i;
+                continue;
+            }
+            if (err != io::EOF_())
+                return err;
+            if (error e = retire(ctx, i, 0))
+                return e;
+        }
+        size_t depth = 0;
+        for (auto &l : lines)
+            depth = std::max(depth, l.r->processors.size());
+        for (size_t p = 0; p < depth; ++p) {
+            std::vector<std::pair<BatchGroup *, std::vector<pending>>> groups;
+            for (size_t i = 0; i < lines.size();) {
+                auto &procs = lines[i].r->processors;
+                if (p >= procs.size()) {
+                    ++i;
+                    continue;
+                }
+                Processor &pr = *procs[p];
+                error err;
+                if (pr.Batch) {
+                    pending pe{&pr, {}};
+                    err = pr.batchBegin(ctx, &pe.pd);
+                    if (!err) {
+                        auto it = std::find_if(groups.begin(), groups.end(),
+                                               [&](const auto &g) { return g.first == pr.Batch.get(); });
+                        if (it == groups.end()) {
+                            groups.emplace_back(pr.Batch.get(), std::vector<pending>{});
+                            it = groups.end() - 1;
+                        }
+                        it->second.push_back(std::move(pe));
+                    }
+                } else {
+                    err = pr.execute(ctx);
+                }
+                if (!err) {
+                    ++i;
+                    continue;
+                }
+                if (err != io::EOF_())
+                    return err;
+                if (error e = retire(ctx, i, p + 1))
+                    return e;
+            }
+            std::vector<Processor *> ended;
+            for (auto &g : groups) {
+                const size_t slots = (size_t)g.first->Slots();
+                std::vector<const signal::Floating *> ins(slots, nullptr);
+                std::vector<signal::Floating *> outs(slots, nullptr);
+                std::vector<int> processed(slots, 0);
+                error procErr;
+                for (auto &pe : g.second) {
+                    const size_t s = (size_t)pe.proc->BatchSlot;
+                    if (s >= slots || ins[s])
+                        procErr = NewError("batch group: bad or duplicate slot");
+                    else {
+                        ins[s] = &pe.pd.m.Signal;
+                        outs[s] = &pe.pd.output;
+                    }
+                }
+                if (!procErr)
+                    procErr = g.first->ProcessLines(ins, outs, &processed);
+                error first;
+                for (auto &pe : g.second) {
+                    const size_t s = (size_t)pe.proc->BatchSlot;
+                    error e = pe.proc->batchEnd(ctx, pe.pd, s < slots ? processed[s] : 0, procErr);
+                    if (e == io::EOF_())
+                        ended.push_back(pe.proc);
+                    else if (e && !first)
+                        first = e;
+                }
+                if (first)
+                    return first;
+            }
+            for (Processor *pr : ended) {  // a Send refused (context done): EOF for that Line
+                for (size_t i = 0; i < lines.size(); ++i)
+                    if (p < lines[i].r->processors.size() && lines[i].r->processors[p].get() == pr) {
+                        if (error e = retire(ctx, i, p + 1))
+                            return e;
+                        break;
+                    }
+            }
+        }
+        for (size_t i = 0; i < lines.size();) {
+            error err = lines[i].r->sink->execute(ctx);
+            if (!err) {
+                ++i;
+                continue;
+            }
+            if (err != io::EOF_())
+                return err;
+            if (error e = retire(ctx, i, lines[i].r->processors.size() + 1))
+                return e;
+        }
+        return lines.empty() ? io::EOF_() : nullptr;
+    }
+};
+
 // run(): sync context                                               run.go:198-224
 error runSync(const Context &ctx, executor &e, ErrorRun *detail)
 {
@@ -557,6 +765,21 @@ error Run(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun 
             return err;
         r->connect(bufferSize);
         e.executors.push_back(makeLineExecutor(r, nullptr, (int)i));
+    }
+    return runSync(ctx, e, detail);
+}
+
+error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail)
+{
+    stageMajorExecutor e;
+    const mut::Context mctx = mut::Mutable();
+    for (size_t i = 0; i < lines.size(); ++i) {
+        lines[i].Context = mctx;
+        std::shared_ptr<route> r;
+        if (error err = bindLine(lines[i], bufferSize, &r))
+            return err;
+        r->connect(bufferSize);
+        e.lines.push_back({r, makeLineExecutor(r, nullptr, (int)i)});
     }
     return runSync(ctx, e, detail);
 }

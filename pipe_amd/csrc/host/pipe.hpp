@@ -165,6 +165,18 @@ struct Source : executor {  // pipe.go:35-43
     error flushHook(const ::pipe::Context &ctx) override;
 };
 
+// A set of identical Processors -- one per Line -- that advance together: ONE device launch
+// per pass for all of them instead of one ProcessFunc call per Line (RunBatched below).
+// Slot i belongs to the Processor that carries BatchSlot == i.
+struct BatchGroup {
+    virtual ~BatchGroup() = default;
+    virtual int Slots() const = 0;
+    // ins[i] / outs[i]: this pass's buffers of slot i, nullptr for a slot that takes no part
+    // (its Line has ended).  processed[i] receives the frames written to outs[i].
+    virtual error ProcessLines(const std::vector<const signal::Floating *> &ins,
+                               const std::vector<signal::Floating *> &outs, std::vector<int> *processed) = 0;
+};
+
 struct Processor : executor {  // pipe.go:52-60
     mut::Context Context;
     ::pipe::ProcessFunc ProcessFunc;
@@ -173,8 +185,20 @@ struct Processor : executor {  // pipe.go:52-60
     ::pipe::SignalProperties SignalProperties;
     in_link in;
     out_link out;
+    // set by a batched allocator: the group this Processor advances with (RunBatched only)
+    std::shared_ptr<BatchGroup> Batch;
+    int BatchSlot = -1;
     void connect(int bufferSize, const fitting::New &fn, const out_link &prev);  // pipe.go:415-421
     error execute(const ::pipe::Context &ctx) override;                          // pipe.go:423-451
+    // execute() split around ProcessFunc for the batched pass: everything before the call
+    // (receive, mutations, output allocation: pipe.go:424-437) / everything after it
+    // (slice, send, free the input: pipe.go:438-450)
+    struct Pending {
+        fitting::Message m;
+        signal::Floating output;
+    };
+    error batchBegin(const ::pipe::Context &ctx, Pending *pd);
+    error batchEnd(const ::pipe::Context &ctx, Pending &pd, int processed, const error &procErr);
     error startHook(const ::pipe::Context &ctx) override;
     error flushHook(const ::pipe::Context &ctx) override;
 };
@@ -211,6 +235,13 @@ inline std::vector<ProcessorAllocatorFunc> Processors(std::vector<ProcessorAlloc
 // Returns nil, a plain error ("error starting ..."), or an ErrorRun rendered as
 // an error whose cause chain keeps the original for Is().
 error Run(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail = nullptr);
+
+// pipe.Run with a STAGE-MAJOR pass: per pass every live Line's Source runs, then stage p of
+// every Line, then every Sink.  Each Line sees exactly the data flow of Run (same buffers, same
+// order within the Line, same EOF/flush/error rules); what changes is the interleaving across
+// Lines, which lets Processors that share a BatchGroup advance with one device launch.
+// Processors without a group execute one by one as in Run.  
+error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail = nullptr);
 
 // pipe.New + Start + Wait: immutable Line context => one thread per component
 // connected by capacity-1 channels; mutable context => sync executor per context.

@@ -13,7 +13,7 @@ from . import _lib
 MAX_PROCS = 8
 PROC_MOCK, PROC_HIP_COPY, PROC_HIP_GAIN, PROC_HIP_FIR, PROC_HIP_BIQUAD, PROC_HIP_CHAIN = range(6)
 SRC_CONST, SRC_SYNTH, SRC_ARRAY = range(3)
-MODE_RUN, MODE_ASYNC = 0, 1
+MODE_RUN, MODE_ASYNC, MODE_RUN_BATCHED = 0, 1, 2
 
 
 class _ProcDesc(C.Structure):

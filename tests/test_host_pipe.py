@@ -190,3 +190,59 @@ def test_hip_processor_error_surfaces_as_run_error():
     err, res = H.run(BUF, [line])
     assert err.failed and err.is_mock_error
     assert res[0].source.flushed and res[0].procs[0].flushed and res[0].sink.flushed
+
+
+# ---------------------------------------------------------- stage-major (batched) Run
+def test_run_batched_equals_run_without_groups():
+    # no BatchGroup anywhere: the stage-major pass must give every Line what pipe.Run gives it
+    lens = [7 * BUF + 77, BUF, 3, 4 * BUF + 1]
+    mk = lambda n, i: dict(limit=n, channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False)
+    a = [H.Line(procs=[H.Proc(H.PROC_MOCK)] * (1 + i % 2), **mk(n, i)) for i, n in enumerate(lens)]
+    b = [H.Line(procs=[H.Proc(H.PROC_MOCK)] * (1 + i % 2), **mk(n, i)) for i, n in enumerate(lens)]
+    e1, r1 = H.run(BUF, a, H.MODE_RUN)
+    e2, r2 = H.run(BUF, b, H.MODE_RUN_BATCHED)
+    assert not e1.failed and not e2.failed, e2.message
+    for x, y in zip(r1, r2):
+        assert np.array_equal(x.values, y.values)
+        for cx, cy in ((x.source, y.source), (x.sink, y.sink), (x.procs[0], y.procs[0])):
+            assert (cx.messages, cx.samples, cx.started, cx.flushed) == (cy.messages, cy.samples, cy.started, cy.flushed)
+
+
+def test_run_batched_error_and_restart_rules():
+    line = H.Line(limit=4 * BUF, channels=1, procs=[H.Proc(H.PROC_MOCK, err_on_call=True)])
+    ok = H.Line(limit=4 * BUF, channels=1, procs=[H.Proc(H.PROC_MOCK)])
+    err, res = H.run(BUF, [ok, line], H.MODE_RUN_BATCHED)
+    assert err.failed and err.is_mock_error
+    for r in res:  # the deferred flush reaches every started component (run.go:207-214)
+        assert r.source.flushed and r.procs[0].flushed and r.sink.flushed
+    err, res = H.run(BUF, [H.Line(limit=862 * BUF, channels=1, procs=[H.Proc(H.PROC_MOCK)])], H.MODE_RUN_BATCHED,
+                     runs=2)
+    assert not err.failed
+    assert (res[0].sink.messages, res[0].sink.samples) == (2 * 862, 2 * 862 * BUF)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("runs", [1, 2])
+def test_batched_chain_lines_equal_oracle_loop(runs):
+    # five Lines of different lengths behind ONE device handle, one launch per pass: each Line
+    # must still get exactly the oracle loop's float64 samples, including its short last buffer
+    # and the Lines that end early (whose slots then idle)
+    C_ = 2
+    taps = synth.fir_lowpass_taps(256)
+    sos = synth.biquad_rbj_lowpass()
+    lens = [9 * BUF + 200, 9 * BUF + 200, 5 * BUF, 77, 6 * BUF + 511]
+    hlines, olines = [], []
+    for i, n in enumerate(lens):
+        hlines.append(H.Line(limit=n, channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                             procs=[H.Proc(H.PROC_HIP_CHAIN, H.chain_params(taps, sos, 0.5)), H.Proc(H.PROC_MOCK)]))
+        olines.append(O.Line(limit=n, channels=C_, src_kind=O.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                             procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_BIQUAD, sos), O.Proc(O.PROC_GAIN, [0.5]),
+                                    O.Proc(O.PROC_COPY)]))
+    herr, hres = H.run(BUF, hlines, H.MODE_RUN_BATCHED, runs=runs)
+    oerr, ores = O.run_lines(BUF, olines)
+    assert not herr.failed, herr.message
+    for h, o, n in zip(hres, ores, lens):
+        assert h.sink.samples == runs * o.sink.samples and h.sink.messages == runs * o.sink.messages
+        # the sink keeps the LAST run's samples: after a restart they are the same samples again,
+        # i.e. StartFunc zeroed the device state of every slot
+        assert np.array_equal(h.values, o.values)
