@@ -95,6 +95,20 @@ def batch(config, what, proc, d_in, d_out, frames, samples, reps=20):
          algorithmic_gb_s=round(samples * 8 / dt / 1e9, 1))
 
 
+def pcie_inclusive(config, what, proc, L_, F, C, dtype=np.float32, reps=30):
+    # the ProcessFunc form with host buffers: memcpy to pinned -> H2D -> kernel(s) -> D2H -> memcpy out,
+    # synchronous, one buffer_size buffer per Line per call, straight through the C ABI
+    import ctypes as CT
+    from pipe_amd import _lib as LIB
+    x = np.full((L_, F, C), 0.25, dtype=dtype)
+    y = np.empty_like(x)
+    n = CT.c_int32()
+    fn = LIB.lib().pipe_hip_process
+    dt = timed(lambda: LIB.check(fn(proc._h, x.ctypes.data, F, y.ctypes.data, F, CT.byref(n)), "process"), reps, 3)
+    emit(config=config, what=what, ms_per_step=round(dt * 1e3, 4), msamples_per_s=round(x.size / dt / 1e6, 1),
+         host_gb_s_each_way=round(x.nbytes / dt / 1e9, 2))
+
+
 def config2():
     F, C, N, L, K = 4096, 2, 256, 64, 64
     taps = synth.fir_lowpass_taps(N, f32_rounded=True)
@@ -107,6 +121,8 @@ def config2():
         batch(2, f"{L} Lines x {K} buffers x 4096x2 f32, FIR-256, one launch per step", p, d_in, d_out, K * F, n)
         p.set_exact(True)
         batch(2, "same, bit-exact direct form", p, d_in, d_out, K * F, n, reps=5)
+        p.set_exact(False)
+        pcie_inclusive(2, f"PCIe-inclusive: pipe_hip_process, {L} Lines x one 4096x2 f32 host buffer each per call", p, L, F, C)
 
 
 def config3():
@@ -122,6 +138,8 @@ def config3():
         p.start()
         batch(3, f"{L} Lines x 8 ch x 4096 frames f32, FIR-256 + biquad + gain chain (f64 intermediates)",
               p, d_in, d_out, F, n, reps=10)
+        pcie_inclusive(3, f"PCIe-inclusive: pipe_hip_process, the same chain from host buffers ({L} Lines x 4096x8 f32)",
+                       p, L, F, C, reps=8)
     for name, mk in (("FIR-256 alone", lambda: P.Fir(taps, F, C, **kw)), ("biquad alone", lambda: P.Biquad(q, F, C, **kw)),
                      ("gain alone", lambda: P.Gain(0.5, F, C, **kw))):
         with mk() as p:
