@@ -182,6 +182,37 @@ struct Pair<double> {
     using type = double2;
 };
 
+// channel-pair access through a buffer resource (offset beyond num_records: loads give 0,
+// stores are dropped)
+template <typename T>
+__device__ __forceinline__ typename Pair<T>::type buf_load_pair(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <>
+__device__ __forceinline__ float2 buf_load_pair<float>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
+template <>
+__device__ __forceinline__ double2 buf_load_pair<double>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+template <typename T>
+__device__ __forceinline__ void buf_store_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, double re, double im);
+template <>
+__device__ __forceinline__ void buf_store_pair<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, double re, double im)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const float2 o{(float)re, (float)im};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), r, voff, 0, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store_pair<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, double re, double im)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const double2 o{re, im};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), r, voff, 0, 0);
+}
+
 struct Args {
     int64_t frames;       // frames per Line in this call
     int64_t line_stride;  // elements between Lines
@@ -191,6 +222,7 @@ struct Args {
     int lines;
     int tiles_per_line;
     int64_t nitems;       // lines * pairs * tiles_per_line
+    int d_pair, d_tile, d_line;  // the wave stride of the launch as (pair, tile, Line) digits
 };
 
 // Lanes of one wave talk through the wave-private buffer.  The hardware keeps a
@@ -241,43 +273,59 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     cd wC{s2.x, s2.y};
 
     using In2 = typename Pair<TIn>::type;
-    using Out2 = typename Pair<TOut>::type;
+    // Item coordinates are wave-uniform and live in SGPRs: (Line, tile, channel pair), channel
+    // pair fastest -- the pairs of one tile read the same cache lines, and neighbouring waves of
+    // a workgroup work on them at the same time.  They advance by the launch's wave stride
+    // without a division (a.d_pair / a.d_tile / a.d_line are that stride's digits).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave_u;
+    const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
     struct Item {
-        int line, c0;
-        bool two, interior;
-        int64_t t0, fr0;
+        int line, tile, pair;
     };
-    auto decode = [&](int64_t item) {
-        Item it;
-        // channel pair fastest: the pairs of one tile read the same cache lines, and
-        // neighbouring waves of a workgroup work on them at the same time
-        const int pair = (int)(item % a.pairs);
-        const int64_t rest = item / a.pairs;
-        const int tile = (int)(rest % a.tiles_per_line);
-        it.line = (int)(rest / a.tiles_per_line);
-        it.c0 = pair * 2;
-        it.two = it.c0 + 1 < a.C;
-        it.t0 = (int64_t)tile * a.L;
-        it.fr0 = it.t0 - a.H;  // frame of window element 0
-        it.interior = it.fr0 >= 0 && it.fr0 + kM - 1 <= last && it.two;
+    Item cur{0, 0, 0};
+    if (wave_global < a.nitems) {
+        cur.pair = __builtin_amdgcn_readfirstlane((int)(wave_global % a.pairs));
+        const int64_t rest = wave_global / a.pairs;
+        cur.tile = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_per_line));
+        cur.line = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_per_line));
+    }
+    auto advance = [&](Item it) {
+        it.pair += a.d_pair;
+        if (it.pair >= a.pairs) {
+            it.pair -= a.pairs;
+            ++it.tile;
+        }
+        it.tile += a.d_tile;
+        if (it.tile >= a.tiles_per_line) {
+            it.tile -= a.tiles_per_line;
+            ++it.line;
+        }
+        it.line += a.d_line;
         return it;
     };
-    // pair loads of an interior window: lane n1, register r -> frame fr0 + n1 + 64 r
+    // VEC windows that start inside the Line (every tile but a Line's first) are read through a
+    // buffer resource based at the window: 32-bit per-lane offsets, no address arithmetic in the
+    // loop, and the frames past the end of the Line read as zero (hardware range check)
+    auto interior = [&](const Item &it) { return VEC && (int64_t)it.tile * a.L - a.H >= 0; };
+    const unsigned in_lane = (unsigned)((n1 * a.C) * sizeof(TIn));    // + c0*sizeof(TIn) per item
+    const unsigned in_step = (unsigned)(64 * a.C * sizeof(TIn));      // 64 frames
+    const unsigned out_step = (unsigned)(64 * a.C * sizeof(TOut));
+    auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
     In2 pf[16];
     auto issue = [&](const Item &it) {
-        const In2 *__restrict__ p = reinterpret_cast<const In2 *>(
-            in_base + (int64_t)it.line * a.line_stride + (it.fr0 + n1) * a.C + it.c0);
-        const int64_t step = (int64_t)32 * a.C;  // 64 frames, in pairs
+        const int64_t fr0 = (int64_t)it.tile * a.L - a.H;
+        const TIn *base = in_base + (int64_t)it.line * a.line_stride + fr0 * a.C;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<TIn *>(base), 0, bytes31((a.frames - fr0) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+        const unsigned v0 = in_lane + (unsigned)(it.pair * 2 * sizeof(TIn));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            pf[r] = p[r * step];
+            pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
     };
 
-    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
-    Item cur = decode(wave_global < a.nitems ? wave_global : 0);
     bool have_pf = false;
-    if (VEC && wave_global < a.nitems && cur.interior) {
+    if (wave_global < a.nitems && interior(cur)) {
         issue(cur);
         have_pf = true;
     }
@@ -286,11 +334,9 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         // powers out of the item loop and spills them
         asm volatile("" : "+v"(wB.re), "+v"(wB.im), "+v"(wC.re), "+v"(wC.im));
         const cd wBc{wB.re, -wB.im}, wCc{wC.re, -wC.im};
-        const int line = cur.line, c0 = cur.c0;
-        const bool two = cur.two;
-        const int64_t t0 = cur.t0, fr0 = cur.fr0;
-        const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-        const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+        const int line = cur.line, c0 = cur.pair * 2;
+        const bool two = c0 + 1 < a.C;
+        const int64_t t0 = (int64_t)cur.tile * a.L, fr0 = t0 - a.H;
 
         // ---- the window: lane n1, register n2 -> element n1 + 64*n2 -------------
         cd v[16];
@@ -298,14 +344,10 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 v[r] = cd{(double)pf[r].x, (double)pf[r].y};
-        } else if (cur.interior) {
-            const TIn *__restrict__ p = in + (fr0 + n1) * a.C + c0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v[r].re = (double)p[(int64_t)r * 64 * a.C];
-                v[r].im = (double)p[(int64_t)r * 64 * a.C + 1];
-            }
         } else {
+            // a Line's first tile (its head is the history) and odd / unaligned layouts
+            const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
+            const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t g = fr0 + n1 + 64 * r;
@@ -327,8 +369,8 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         // next item's window: in flight while this one is transformed
         have_pf = false;
         if (item + wave_stride < a.nitems) {
-            cur = decode(item + wave_stride);
-            if (VEC && cur.interior) {
+            cur = advance(cur);
+            if (interior(cur)) {
                 issue(cur);
                 have_pf = true;
             }
@@ -402,18 +444,26 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         dft16<+1>(v);    // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
 
         // ---- store the valid part: window index i >= H is frame t0 + i - H ------
-        TOut *__restrict__ out = out_base + (int64_t)line * a.line_stride;
+        if constexpr (VEC) {
+            // buffer resource based at the tile's first output frame: the frames past the end of
+            // the Line fall outside it and are dropped; window indices below H get an offset
+            // outside it too
+            TOut *base = out_base + (int64_t)line * a.line_stride + t0 * a.C;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                base, 0, bytes31((a.frames - t0) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
+            const int o0 = ((n1 - a.H) * a.C + c0) * (int)sizeof(TOut);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = n1 + 64 * r;
-            const int64_t g = t0 + i - a.H;
-            if (i >= a.H && g <= last) {
-                if (VEC && two) {
-                    Out2 o;
-                    o.x = (TOut)v[r].re;
-                    o.y = (TOut)v[r].im;
-                    *reinterpret_cast<Out2 *>(out + g * a.C + c0) = o;
-                } else {
+            for (int r = 0; r < 16; ++r) {
+                const int off = o0 + r * (int)out_step;
+                buf_store_pair<TOut>(rs, off >= 0 ? (unsigned)off : 0xFFFFFFFFu, v[r].re, v[r].im);
+            }
+        } else {
+            TOut *__restrict__ out = out_base + (int64_t)line * a.line_stride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = n1 + 64 * r;
+                const int64_t g = t0 + i - a.H;
+                if (i >= a.H && g <= last) {
                     out[g * a.C + c0] = (TOut)v[r].re;
                     if (two)
                         out[g * a.C + c0 + 1] = (TOut)v[r].im;
@@ -515,7 +565,7 @@ int64_t Plan::items(int64_t frames, int channels, int lines) const
 }
 
 template <typename TIn, typename TOut, int WAVES, bool VEC>
-static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, const Args &a,
+static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, Args a,
                       hipStream_t s)
 {
     auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
@@ -532,6 +582,10 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
     const int64_t per = (a.nitems + slots - 1) / slots;     // items per wave
     const int64_t waves = (a.nitems + per - 1) / per;
     const unsigned grid = (unsigned)((waves + WAVES - 1) / WAVES);
+    const int64_t stride = (int64_t)grid * WAVES;
+    a.d_pair = (int)(stride % a.pairs);
+    a.d_tile = (int)((stride / a.pairs) % a.tiles_per_line);
+    a.d_line = (int)(stride / a.pairs / a.tiles_per_line);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, s, static_cast<const TIn *>(d_in),
                        static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw1.p),
                        static_cast<const double2 *>(I.tw2.p), static_cast<const double2 *>(I.hperm[I.cur].p), a);
