@@ -67,9 +67,16 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # RCCL only for the barrier and the max-over-ranks: Lines do not communicate.
+    # PIPE_BENCH_DIST_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks
+    # then share devices, so its numbers mean nothing): it exercises the rank / barrier / reduce
+    # logic of this file end to end.
+    backend = os.environ.get("PIPE_BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-    # RCCL only for the barrier and the max-over-ranks: Lines do not communicate
-    dist = shard.init("nccl", rank, world, device=torch.device("cuda", local))
+    dist = shard.init(backend, rank, world, device=torch.device("cuda", local) if backend == "nccl" else None)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -113,7 +120,7 @@ def main():
     fir.set_profiling(False)
     kname = fir.kernel_name()
 
-    elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = shard.max_over_ranks(elapsed, dist, device=reduce_device)
 
     # a cheap self-check that work really happened: DC gain of the filter is 1, so
     # the output mean tracks the input mean (no oracle here: that is tests/ + smoke())
