@@ -53,9 +53,11 @@ typedef enum pipe_hip_param {
     PIPE_HIP_PARAM_GAIN = 0,   /* 1 value                          */
     PIPE_HIP_PARAM_TAPS = 1,   /* ntaps values (count must match)  */
     PIPE_HIP_PARAM_COEFFS = 2, /* nsections*5 values {b0,b1,b2,a1,a2} */
-    PIPE_HIP_PARAM_EXACT = 3   /* 1 value: != 0 pins the FIR to the ordered-fma direct form
-                                  (bit-exact vs the oracle) even for large float32 batches,
-                                  which otherwise use the overlap-save FFT form (<= 1 ulp f32) */
+    PIPE_HIP_PARAM_EXACT = 3   /* 1 value: != 0 pins the stage to its ordered-fma form (bit-exact vs
+                                  the oracle) even for float32 results, which otherwise may use the
+                                  FIR's overlap-save FFT form / the biquad's time-segmented form
+                                  (both <= 1 ulp f32).  float64 buffers always take the exact form.
+                                  On a chain it applies to every stage. */
 } pipe_hip_param;
 
 /* Opaque Processor handle: the state a Go closure would capture. */

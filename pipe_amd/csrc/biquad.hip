@@ -15,6 +15,25 @@
 // An optional gain (the stage that follows a biquad in BASELINE config 3) is
 // applied to the float64 result in the same pass: y_out = y * g, exactly the
 // arithmetic of a separate gain stage reading float64.
+//
+// Time-segmented form (float32 results only, never float64 buffers, never when the handle
+// asks for bit-exactness): 4096 series are 64 waves -- 6 % of the chip.  The recurrence is
+// linear in its state, so the call is cut into T segments per series and run as three launches
+// that fill the machine:
+//   1. every (series, segment) runs the recurrence from a ZERO state and keeps only its end
+//      state z_k                                        (parallel over series x segments)
+//   2. per series, the true incoming state of every segment follows from
+//      s_{k+1} = z_k + M s_k, M = the zero-input state transition over one segment
+//      (2S x 2S, computed on the host from the coefficients)       (T short serial steps)
+//   3. every (series, segment) runs the SAME ordered fma recurrence as the exact kernel,
+//      started from s_k, and stores its outputs          (parallel over series x segments)
+// Pass 3 is the exact arithmetic given its start state; the start states carry the
+// O(1e-16) relative rounding difference of step 2's reassociation, which a stable filter
+// damps.  The float32 result therefore equals the oracle's except where the float64 value
+// sits within ~1e-15 of a rounding boundary (then: the neighbouring float32, 1 ulp) -- the same
+// contract as the FIR's overlap-save form ("the one tolerance").
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -34,7 +53,20 @@ struct BiquadArgs {
     int C, S, nseries;
     double gain;
     int64_t in_bytes, out_bytes;  // extent of the call's buffers (< 4 GiB)
+    // time-segmented form
+    double *seg;      // [T][nseries][S][2]: end states of pass 1, start states after pass 2
+    int seglen, T;    // frames per segment (the last one may be shorter), segments per series
+    int blocks_per_seg;
 };
+
+// zero-input state transition over one segment, row-major (2S x 2S); a kernel argument, so the
+// segmented form is offered up to kMaxSegSections sections
+constexpr int kMaxSegSections = 4;
+struct BiquadTransition {
+    double m[2 * kMaxSegSections][2 * kMaxSegSections];
+};
+
+enum { kWhole = 0, kSegZeroState = 1, kSegFinal = 2 };
 
 template <int NS>
 __device__ __forceinline__ double biquad_step(double x, double (&s1)[kMaxSections],
@@ -78,25 +110,34 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned vof
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
 }
 
-// NS = compile-time section count (1, 2) or 0 = runtime a.S; GAIN = a gain is folded in
-template <typename TIn, typename TOut, int NS, bool GAIN>
+// NS = compile-time section count (1, 2) or 0 = runtime a.S; GAIN = a gain is folded in;
+// MODE: the whole call per series (exact form), or one segment of it (passes 1 and 3 above)
+template <typename TIn, typename TOut, int NS, bool GAIN, int MODE>
 __global__ void __launch_bounds__(kThreads)
 biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a,
               const BiquadCoeffs q)
 {
-    const int sid = blockIdx.x * kThreads + threadIdx.x;
+    // a workgroup never straddles two segments, so the frame count is wave-uniform
+    const int seg = MODE == kWhole ? 0 : (int)(blockIdx.x / (unsigned)a.blocks_per_seg);
+    const int sblock = MODE == kWhole ? (int)blockIdx.x : (int)(blockIdx.x % (unsigned)a.blocks_per_seg);
+    const int sid = sblock * kThreads + threadIdx.x;
     const bool live = sid < a.nseries;
     const int sidc = live ? sid : 0;
     const int line = sidc / a.C;
     const int c = sidc - line * a.C;
-    double *__restrict__ st = a.state + (int64_t)sidc * a.S * 2;
+    double *__restrict__ st = MODE == kWhole ? a.state + (int64_t)sidc * a.S * 2
+                                             : a.seg + ((int64_t)seg * a.nseries + sidc) * a.S * 2;
+    const int64_t f_first = (int64_t)seg * a.seglen;
+    const int64_t nframes = MODE == kWhole ? a.frames
+                                           : (a.frames - f_first < a.seglen ? a.frames - f_first : (int64_t)a.seglen);
     // whole call through 32-bit offsets (the launcher guarantees the buffers are < 4 GiB)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<TIn *>(in_base), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, (int)a.out_bytes, 0x00020000);
     // dead lanes point past the end: their loads return 0 and their stores are dropped
-    const unsigned vin = live ? (unsigned)(((int64_t)line * a.frames * a.C + c) * sizeof(TIn)) : 0xFFFFFFFFu;
-    const unsigned vout = live ? (unsigned)(((int64_t)line * a.frames * a.C + c) * sizeof(TOut)) : 0xFFFFFFFFu;
+    const int64_t e0 = ((int64_t)line * a.frames + f_first) * a.C + c;  // first element of this lane
+    const unsigned vin = live ? (unsigned)(e0 * sizeof(TIn)) : 0xFFFFFFFFu;
+    const unsigned vout = live ? (unsigned)(e0 * sizeof(TOut)) : 0xFFFFFFFFu;
     const unsigned sin_step = (unsigned)(a.C * sizeof(TIn));    // bytes per frame
     const unsigned sout_step = (unsigned)(a.C * sizeof(TOut));
 
@@ -105,7 +146,7 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
     for (int s = 0; s < kMaxSections; ++s) {
         s1[s] = 0.0;
         s2[s] = 0.0;
-        if (live && s < a.S) {
+        if (MODE != kSegZeroState && live && s < a.S) {
             s1[s] = st[2 * s];
             s2[s] = st[2 * s + 1];
         }
@@ -128,14 +169,14 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
                 }
             }
         }
-        if constexpr (GAIN)
+        if constexpr (GAIN && MODE != kSegZeroState)
             y = y * a.gain;
         return y;
     };
 
     // two chunks in flight: chunk k+1 is loading while the dependent chain walks chunk k
     // (series are scarce -- 64 waves for 4096 series -- so no other wave hides the latency)
-    const int64_t nchunks = a.frames / kChunk;
+    const int64_t nchunks = nframes / kChunk;
     TIn xa[kChunk], xb[kChunk];
     if (nchunks > 0) {
 #pragma unroll
@@ -147,10 +188,15 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
 #pragma unroll
         for (int u = 0; u < kChunk; ++u)
             y[u] = (TOut)step((double)x[u]);
-        const unsigned so = (unsigned)f0 * sout_step;
+        if constexpr (MODE == kSegZeroState) {
+            // only the end state matters; keep the chain alive without a store
+            asm volatile("" ::"v"(y[kChunk - 1]));
+        } else {
+            const unsigned so = (unsigned)f0 * sout_step;
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u)
-            buf_store(rout, vout, so + (unsigned)u * sout_step, y[u]);
+            for (int u = 0; u < kChunk; ++u)
+                buf_store(rout, vout, so + (unsigned)u * sout_step, y[u]);
+        }
     };
     int64_t k = 0;
     for (; k + 2 <= nchunks; k += 2) {
@@ -169,12 +215,13 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
     }
     if (k < nchunks)
         run_chunk(xa, k * kChunk);
-    for (int64_t f = nchunks * kChunk; f < a.frames; ++f) {
+    for (int64_t f = nchunks * kChunk; f < nframes; ++f) {
         const double y = step((double)buf_load<TIn>(rin, vin, (unsigned)f * sin_step));
-        buf_store(rout, vout, (unsigned)f * sout_step, (TOut)y);
+        if constexpr (MODE != kSegZeroState)
+            buf_store(rout, vout, (unsigned)f * sout_step, (TOut)y);
     }
 
-    if (live) {
+    if (MODE != kSegFinal && live) {
 #pragma unroll
         for (int s = 0; s < kMaxSections; ++s) {
             if (s < a.S) {
@@ -183,6 +230,61 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
             }
         }
     }
+}
+
+// pass 2: per series, turn the zero-state end states z_k into the true start states s_k
+// (in place) and leave the state after the last segment in the persistent state array.
+// N = 2S states.  The z_k of kScanChunk segments are fetched together (independent loads), so
+// the serial part is arithmetic only.
+constexpr int kScanChunk = 16;
+template <int N>
+__global__ void __launch_bounds__(kThreads)
+biquad_scan_kernel(const BiquadArgs a, const BiquadTransition mfull, const BiquadTransition mlast)
+{
+    const int sid = blockIdx.x * kThreads + threadIdx.x;
+    if (sid >= a.nseries)
+        return;
+    double s[N];
+    double *__restrict__ st = a.state + (int64_t)sid * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        s[i] = st[i];
+    const int64_t stride = (int64_t)a.nseries * N;  // doubles between segments
+    double *__restrict__ zbase = a.seg + (int64_t)sid * N;
+    for (int k0 = 0; k0 < a.T; k0 += kScanChunk) {
+        double z[kScanChunk][N];
+#pragma unroll
+        for (int u = 0; u < kScanChunk; ++u) {
+            const int k = k0 + u < a.T ? k0 + u : a.T - 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                z[u][i] = zbase[k * stride + i];
+        }
+#pragma unroll
+        for (int u = 0; u < kScanChunk; ++u) {
+            const int k = k0 + u;
+            if (k < a.T) {
+                const BiquadTransition &m = k == a.T - 1 ? mlast : mfull;
+                double nx[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = z[u][i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        acc = __builtin_fma(m.m[i][j], s[j], acc);
+                    nx[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    zbase[k * stride + i] = s[i];
+                    s[i] = nx[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        st[i] = s[i];
 }
 
 class Biquad final : public pipe_hip_processor {
@@ -203,9 +305,14 @@ public:
     }
     int set_param(int32_t param, const double *values, int32_t count) override
     {
+        if (param == PIPE_HIP_PARAM_EXACT && count == 1 && values) {
+            exact_ = values[0] != 0.0;
+            return PIPE_HIP_OK;
+        }
         if (param != PIPE_HIP_PARAM_COEFFS || count != 5 * S_ || !values)
             return PIPE_HIP_EINVAL;
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
+        mfull_len_ = -1;
         return PIPE_HIP_OK;
     }
     // a gain stage that directly follows this biquad in a chain is folded into the
@@ -232,41 +339,148 @@ public:
         a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * cfg.lines;
         if (a.in_bytes >= ((int64_t)1 << 32) - 4096 || a.out_bytes >= ((int64_t)1 << 32) - 4096)
             return PIPE_HIP_EINVAL;  // 32-bit buffer offsets: split the call (never reached by buffer_size*max_batch in practice)
-        const dim3 grid((unsigned)((a.nseries + kThreads - 1) / kThreads));
+        const unsigned sblocks = (unsigned)((a.nseries + kThreads - 1) / kThreads);
+        // time-segmented form: float32 results (or float64 intermediates of a float32 chain)
+        // only, and only when the series alone cannot fill the machine
+        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out);
+        // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
+        bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
+                         frames * a.nseries >= seg_min_samples_;
+        if (segmented) {
+            int T = (int)(frames / 64);
+            T = T < 2 ? 2 : (T > 1024 ? 1024 : T);
+            int64_t seglen = (frames + T - 1) / T;
+            seglen = (seglen + kChunk - 1) / kChunk * kChunk;
+            T = (int)((frames + seglen - 1) / seglen);
+            segmented = T >= 2;
+            a.seglen = (int)seglen;
+            a.T = T;
+            a.blocks_per_seg = (int)sblocks;
+        }
         PH_TRY(timer.begin(s));
-#define PH_BQ2(TI, TO, G)                                                                           \
-    do {                                                                                            \
-        if (S_ == 1)                                                                                \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 1, G>), grid, dim3(kThreads), 0, s,           \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
-        else if (S_ == 2)                                                                           \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 2, G>), grid, dim3(kThreads), 0, s,           \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
-        else                                                                                        \
-            hipLaunchKernelGGL((biquad_kernel<TI, TO, 0, G>), grid, dim3(kThreads), 0, s,           \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);     \
+        if (segmented) {
+            const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
+            if (seg_.bytes < need)
+                PH_TRY(seg_.alloc(need));
+            a.seg = static_cast<double *>(seg_.p);
+            if (mfull_len_ != a.seglen) {
+                transition(a.seglen, &mfull_);
+                mfull_len_ = a.seglen;
+            }
+            BiquadTransition mlast;
+            const int64_t last_len = frames - (int64_t)(a.T - 1) * a.seglen;
+            if (last_len == a.seglen)
+                mlast = mfull_;
+            else
+                transition((int)last_len, &mlast);
+            const dim3 sgrid(sblocks * (unsigned)a.T);
+#define PH_BQ3(TI, TO, NSV, G)                                                                         \
+    do {                                                                                               \
+        hipLaunchKernelGGL((biquad_kernel<TI, TO, NSV, G, kSegZeroState>), sgrid, dim3(kThreads), 0, s, \
+                           static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);            \
+        launch_scan(sblocks, s, a, mlast);                                                             \
+        hipLaunchKernelGGL((biquad_kernel<TI, TO, NSV, G, kSegFinal>), sgrid, dim3(kThreads), 0, s,     \
+                           static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);            \
     } while (0)
-#define PH_BQ(TI, TO, NAME)                                                                         \
-    do {                                                                                            \
-        if (has_gain_)                                                                              \
-            PH_BQ2(TI, TO, true);                                                                   \
-        else                                                                                        \
-            PH_BQ2(TI, TO, false);                                                                  \
-        last_kernel = NAME;                                                                         \
+#define PH_BQ2(TI, TO, G)              \
+    do {                               \
+        if (S_ == 1)                   \
+            PH_BQ3(TI, TO, 1, G);      \
+        else if (S_ == 2)              \
+            PH_BQ3(TI, TO, 2, G);      \
+        else                           \
+            PH_BQ3(TI, TO, 0, G);      \
     } while (0)
-        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
-            PH_BQ(float, float, "biquad_kernel<f32,f32>");
-        else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
-            PH_BQ(double, double, "biquad_kernel<f64,f64>");
-        else if (in_dtype == PIPE_HIP_F32)
-            PH_BQ(float, double, "biquad_kernel<f32,f64>");
-        else
-            PH_BQ(double, float, "biquad_kernel<f64,f32>");
+#define PH_BQ(TI, TO, NAME)            \
+    do {                               \
+        if (has_gain_)                 \
+            PH_BQ2(TI, TO, true);      \
+        else                           \
+            PH_BQ2(TI, TO, false);     \
+        last_kernel = NAME;            \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_BQ(float, float, "biquad_kernel<f32,f32,segmented>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_BQ(double, double, "biquad_kernel<f64,f64,segmented>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_BQ(float, double, "biquad_kernel<f32,f64,segmented>");
+            else
+                PH_BQ(double, float, "biquad_kernel<f64,f32,segmented>");
 #undef PH_BQ
 #undef PH_BQ2
+#undef PH_BQ3
+        } else {
+            const dim3 grid(sblocks);
+#define PH_BQ2(TI, TO, G)                                                                              \
+    do {                                                                                               \
+        if (S_ == 1)                                                                                   \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 1, G, kWhole>), grid, dim3(kThreads), 0, s,      \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);        \
+        else if (S_ == 2)                                                                              \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 2, G, kWhole>), grid, dim3(kThreads), 0, s,      \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);        \
+        else                                                                                           \
+            hipLaunchKernelGGL((biquad_kernel<TI, TO, 0, G, kWhole>), grid, dim3(kThreads), 0, s,      \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), a, q_);        \
+    } while (0)
+#define PH_BQ(TI, TO, NAME)            \
+    do {                               \
+        if (has_gain_)                 \
+            PH_BQ2(TI, TO, true);      \
+        else                           \
+            PH_BQ2(TI, TO, false);     \
+        last_kernel = NAME;            \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_BQ(float, float, "biquad_kernel<f32,f32>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_BQ(double, double, "biquad_kernel<f64,f64>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_BQ(float, double, "biquad_kernel<f32,f64>");
+            else
+                PH_BQ(double, float, "biquad_kernel<f64,f32>");
+#undef PH_BQ
+#undef PH_BQ2
+        }
         PH_HIP(hipGetLastError());
         PH_TRY(timer.end(s));
         return PIPE_HIP_OK;
+    }
+
+    void launch_scan(unsigned sblocks, hipStream_t s, const BiquadArgs &a, const BiquadTransition &mlast)
+    {
+        switch (S_) {
+        case 1: hipLaunchKernelGGL(biquad_scan_kernel<2>, dim3(sblocks), dim3(kThreads), 0, s, a, mfull_, mlast); break;
+        case 2: hipLaunchKernelGGL(biquad_scan_kernel<4>, dim3(sblocks), dim3(kThreads), 0, s, a, mfull_, mlast); break;
+        case 3: hipLaunchKernelGGL(biquad_scan_kernel<6>, dim3(sblocks), dim3(kThreads), 0, s, a, mfull_, mlast); break;
+        default: hipLaunchKernelGGL(biquad_scan_kernel<8>, dim3(sblocks), dim3(kThreads), 0, s, a, mfull_, mlast); break;
+        }
+    }
+
+    // zero-input transition of the cascade over `len` frames: column j = the state after len
+    // frames of silence started from unit state j (order s1_0, s2_0, s1_1, s2_1, ...)
+    void transition(int len, BiquadTransition *m) const
+    {
+        const int n = 2 * S_;
+        std::memset(m, 0, sizeof *m);
+        for (int j = 0; j < n; ++j) {
+            long double st[2 * kMaxSections] = {0};
+            st[j] = 1.0L;
+            for (int f = 0; f < len; ++f) {
+                long double x = 0.0L;
+                for (int sct = 0; sct < S_; ++sct) {
+                    const long double b0 = q_.c[sct][0], b1 = q_.c[sct][1], b2 = q_.c[sct][2];
+                    const long double a1 = q_.c[sct][3], a2 = q_.c[sct][4];
+                    const long double y = b0 * x + st[2 * sct];
+                    st[2 * sct] = -a1 * y + (b1 * x + st[2 * sct + 1]);
+                    st[2 * sct + 1] = -a2 * y + b2 * x;
+                    x = y;
+                }
+            }
+            for (int i = 0; i < n; ++i)
+                m->m[i][j] = (double)st[i];
+        }
     }
 
 private:
@@ -274,8 +488,15 @@ private:
     bool has_gain_ = false;
     double gain_ = 1.0;
     BiquadCoeffs q_{};
-    DevBuf state_;
+    DevBuf state_, seg_;
     size_t state_bytes_ = 0;
+    bool exact_ = false;
+    const bool env_exact_ = std::getenv("PIPE_HIP_BIQUAD_EXACT") != nullptr;
+    const int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
+                                         ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))
+                                         : (int64_t)1 << 20;
+    BiquadTransition mfull_{};
+    int mfull_len_ = -1;
 };
 
 }  // namespace

@@ -69,6 +69,13 @@ public:
     // a mutation addressed to the chain goes to the first stage that owns the parameter
     int set_param(int32_t param, const double *values, int32_t count) override
     {
+        if (param == PIPE_HIP_PARAM_EXACT) {  // applies to every stage that has a relaxed form
+            int rc = PIPE_HIP_EINVAL;
+            for (auto &st : stages)
+                if (st->set_param(param, values, count) == PIPE_HIP_OK)
+                    rc = PIPE_HIP_OK;
+            return rc;
+        }
         for (auto &st : stages)
             if (st->set_param(param, values, count) == PIPE_HIP_OK)
                 return PIPE_HIP_OK;

@@ -208,6 +208,11 @@ class Biquad(Processor):
     def set_coeffs(self, coeffs):
         self._set_param(L.PARAM_COEFFS, coeffs)
 
+    def set_exact(self, exact: bool):
+        """True pins the one-lane-per-series ordered recurrence (bit-exact); False (default) lets
+        float32 results use the time-segmented form (<= 1 ulp float32)."""
+        self._set_param(L.PARAM_EXACT, [1.0 if exact else 0.0])
+
 
 class Resampler(Processor):
     def __init__(self, proto, taps_per_phase: int, up: int, down: int, buffer_size: int,

@@ -6,7 +6,7 @@ import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pipe_amd import host as H, synth  # noqa: E402
 
 
