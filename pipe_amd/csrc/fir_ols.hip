@@ -610,11 +610,8 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     // pairs are naturally aligned when the channel count is even and the buffers are
     const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
-    const char *wenv = std::getenv("PIPE_HIP_OLS_WAVES");  // tuning knob
-    const int W = wenv ? std::atoi(wenv) : 8;
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32>";
-        (void)W;
         if (vec)
             return launch_ols<float, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
