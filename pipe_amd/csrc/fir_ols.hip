@@ -39,6 +39,7 @@ namespace ols {
 namespace {
 
 constexpr int kM = 1024;         // FFT size
+constexpr int kVecWaves = 16;    // waves per workgroup (= per CU) of the even-channel kernels: 4 per SIMD
 constexpr int kEx = 1088;        // complex elements per wave-private exchange buffer
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
@@ -244,6 +245,9 @@ __device__ __forceinline__ int ex2_addr(int a, int d, int k2) { return 272 * a +
 // VEC: the channel count is even, so a channel pair is one naturally aligned 8/16-byte
 // element: window loads and result stores move whole pairs, and the next item's window is
 // prefetched into registers while the current one is transformed.
+// WAVES > 8 (three waves per SIMD): the exchange buffers shrink to one float64 plane per wave
+// (real and imaginary parts go through it one after the other) and the register prefetch of
+// the next window is dropped -- the third wave hides that latency instead.
 template <typename TIn, typename TOut, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64)
 fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
@@ -252,6 +256,8 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double2 *hperm = reinterpret_cast<double2 *>(smem_raw);  // [16][64] tap spectrum, kernel layout
+    constexpr bool SPLIT = WAVES > 8;
+    constexpr bool PREFETCH = WAVES <= 8;
     double2 *exbase = hperm + 16 * 64;                       // [WAVES][kEx] wave-private exchange
 
     for (int i = threadIdx.x; i < 16 * 64; i += WAVES * 64)
@@ -260,7 +266,9 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    double2 *E = exbase + wave * kEx;
+    double2 *E = SPLIT ? reinterpret_cast<double2 *>(reinterpret_cast<double *>(exbase) + wave * kEx)
+                       : exbase + wave * kEx;
+    double *Ed = reinterpret_cast<double *>(E);
     // lane roles
     const int n1 = lane;                        // L0
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
@@ -324,8 +332,46 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
     };
 
+    // one exchange: v[r] goes to wr(r), then v[r] is re-read from rd(r)
+    auto exchange = [&](cd (&v)[16], auto wr, auto rd) {
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                E[wr(r)] = double2{v[r].re, v[r].im};
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double2 t = E[rd(r)];
+                v[r] = cd{t.x, t.y};
+            }
+            wave_fence();
+        } else {
+            double re[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ed[wr(r)] = v[r].re;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                re[r] = Ed[rd(r)];
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ed[wr(r)] = v[r].im;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = cd{re[r], Ed[rd(r)]};
+            wave_fence();
+        }
+    };
+    auto x1_lane = [&](int r) { return ex1_addr(n1, r); };                     // (lane n1, reg k2)
+    auto x1_grp = [&](int r) { return ex1_addr(al + 4 * r, k2l); };            // (lane k2 + 16a, reg b)
+    auto x2_grp = [&](int r) { return ex2_addr(al, r, k2l); };                 // (lane k2 + 16a, reg d)
+    auto x2_fin = [&](int r) { return ex2_addr(r & 3, dl, kkl + 4 * (r >> 2)); };  // (lane d + 16kk, reg 4q + a)
+
     bool have_pf = false;
-    if (wave_global < a.nitems && interior(cur)) {
+    if (PREFETCH && wave_global < a.nitems && interior(cur)) {
         issue(cur);
         have_pf = true;
     }
@@ -340,6 +386,10 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 
         // ---- the window: lane n1, register n2 -> element n1 + 64*n2 -------------
         cd v[16];
+        if (!PREFETCH && interior(cur)) {
+            issue(cur);
+            have_pf = true;
+        }
         if (have_pf) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -370,7 +420,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         have_pf = false;
         if (item + wave_stride < a.nitems) {
             cur = advance(cur);
-            if (interior(cur)) {
+            if (PREFETCH && interior(cur)) {
                 issue(cur);
                 have_pf = true;
             }
@@ -380,29 +430,11 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         dft16<-1>(v);    // A: over n2 -> k2
         apply_powers(v, wB);       // B: W1024^(n1*k2)
         // X1: (lane n1, reg k2) -> (lane k2 + 16a, reg b) holding element (a + 4b, k2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex1_addr(n1, r)] = double2{v[r].re, v[r].im};
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double2 t = E[ex1_addr(al + 4 * r, k2l)];
-            v[r] = cd{t.x, t.y};
-        }
-        wave_fence();
+        exchange(v, x1_lane, x1_grp);
         dft16<-1>(v);    // C1: over b -> d
         apply_powers(v, wC);       // C2: W64^(a*d)
         // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex2_addr(al, r, k2l)] = double2{v[r].re, v[r].im};
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double2 t = E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))];
-            v[r] = cd{t.x, t.y};
-        }
-        wave_fence();
+        exchange(v, x2_grp, x2_fin);
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
             dft4<-1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -418,28 +450,10 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex2_addr(r & 3, dl, kkl + 4 * (r >> 2))] = double2{v[r].re, v[r].im};
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double2 t = E[ex2_addr(al, r, k2l)];
-            v[r] = cd{t.x, t.y};
-        }
-        wave_fence();
+        exchange(v, x2_fin, x2_grp);
         apply_powers(v, wCc);
         dft16<+1>(v);    // over d -> b
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            E[ex1_addr(al + 4 * r, k2l)] = double2{v[r].re, v[r].im};
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double2 t = E[ex1_addr(n1, r)];
-            v[r] = cd{t.x, t.y};
-        }
-        wave_fence();
+        exchange(v, x1_grp, x1_lane);
         apply_powers(v, wBc);
         dft16<+1>(v);    // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
 
@@ -569,7 +583,7 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
                       hipStream_t s)
 {
     auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
-    const size_t lds = sizeof(double2) * (16 * 64) + sizeof(double2) * (size_t)kEx * WAVES;
+    const size_t lds = sizeof(double2) * (16 * 64) + (WAVES > 8 ? sizeof(double) : sizeof(double2)) * (size_t)kEx * WAVES;
     if (lds > 64 * 1024)
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -613,26 +627,26 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32>";
         if (vec)
-            return launch_ols<float, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<float, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f64,f32>";
         if (vec)
-            return launch_ols<double, float, 8, true>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<double, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     // float64 output: only as an intermediate of a chain that ends in float32
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f32,f64>";
         if (vec)
-            return launch_ols<float, double, 8, true>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<float, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<float, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f64,f64>";
         if (vec)
-            return launch_ols<double, double, 8, true>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<double, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
         return launch_ols<double, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
     }
     return PIPE_HIP_EINVAL;
