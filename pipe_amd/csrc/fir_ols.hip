@@ -224,6 +224,7 @@ struct Args {
     int tiles_per_line;
     int64_t nitems;       // lines * pairs * tiles_per_line
     int d_pair, d_tile, d_line;  // the wave stride of the launch as (pair, tile, Line) digits
+    int group;                   // waves of a block that take consecutive items
 };
 
 // Lanes of one wave talk through the wave-private buffer.  The hardware keeps a
@@ -286,7 +287,13 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     // a workgroup work on them at the same time.  They advance by the launch's wave stride
     // without a division (a.d_pair / a.d_tile / a.d_line are that stride's digits).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave_u;
+    // wave w of block b starts at item (w / G)*(blocks*G) + b*G + w % G: groups of G = a.group
+    // neighbouring waves take neighbouring items (the channel pairs of one tile), and the groups
+    // are dealt block after block -- so when the items do not divide evenly by the resident
+    // waves, the waves with one item more are spread over all CUs (and SIMDs) instead of filling
+    // the first blocks
+    const int64_t wave_global = (int64_t)(wave_u / a.group) * ((int64_t)gridDim.x * a.group) +
+                                (int64_t)blockIdx.x * a.group + wave_u % a.group;
     const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
     struct Item {
         int line, tile, pair;
@@ -592,10 +599,15 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
         (void)hipGetLastError();
         per_cu = 1;
     }
-    const int64_t slots = (int64_t)per_cu * I.cus * WAVES;  // resident waves
-    const int64_t per = (a.nitems + slots - 1) / slots;     // items per wave
-    const int64_t waves = (a.nitems + per - 1) / per;
-    const unsigned grid = (unsigned)((waves + WAVES - 1) / WAVES);
+    // every CU gets a block (or as many blocks as there are items for); waves walk the items
+    // with the grid's wave stride
+    const int64_t resident = (int64_t)per_cu * I.cus;
+    const int64_t wanted = (a.nitems + WAVES - 1) / WAVES;
+    const unsigned grid = (unsigned)(wanted < resident ? wanted : resident);
+    int group = 1;
+    while (group < a.pairs && group < WAVES)
+        group *= 2;
+    a.group = group;
     const int64_t stride = (int64_t)grid * WAVES;
     a.d_pair = (int)(stride % a.pairs);
     a.d_tile = (int)((stride / a.pairs) % a.tiles_per_line);

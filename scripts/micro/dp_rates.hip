@@ -19,6 +19,10 @@ __global__ void __launch_bounds__(256) k(double *out, int iters)
             asm volatile(".rept 8\n .irp i,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n v_fma_f64 v[4*\\i:4*\\i+1], v[66+4*\\i:66+4*\\i+1], 1.0, v[4*\\i:4*\\i+1]\n .endr\n .endr\n" ::: "memory");
         else if (OP == 5)  // 32-bit v_mov for reference
             asm volatile(".rept 8\n .irp i,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n v_mov_b32 v[4*\\i], v[66+4*\\i]\n .endr\n .endr\n" ::: "memory");
+        else if (OP == 6)
+            asm volatile(".rept 8\n .irp i,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n v_cvt_f64_f32 v[4*\\i:4*\\i+1], v[66+4*\\i]\n .endr\n .endr\n" ::: "memory");
+        else if (OP == 7)
+            asm volatile(".rept 8\n .irp i,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n v_cvt_f32_f64 v[4*\\i], v[66+4*\\i:66+4*\\i+1]\n .endr\n .endr\n" ::: "memory");
     }
     if (iters < 0)
         out[threadIdx.x] = 1.0;
@@ -51,10 +55,10 @@ double run(int wps, int iters)
 int main()
 {
     const int iters = 20000;
-    const char *names[] = {"v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64", "v_fma_f64(x,1.0,y)", "v_mov_b32"};
-    for (int w = 1; w <= 2; ++w) {
-        double r[6] = {run<0>(w, iters), run<1>(w, iters), run<2>(w, iters), run<3>(w, iters), run<4>(w, iters), run<5>(w, iters)};
-        for (int i = 0; i < 6; ++i)
+    const char *names[] = {"v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64", "v_fma_f64(x,1.0,y)", "v_mov_b32", "v_cvt_f64_f32", "v_cvt_f32_f64"};
+    for (int w = 1; w <= 4; w *= 2) {
+        double r[8] = {run<0>(w, iters), run<1>(w, iters), run<2>(w, iters), run<3>(w, iters), run<4>(w, iters), run<5>(w, iters), run<6>(w, iters), run<7>(w, iters)};
+        for (int i = 0; i < 8; ++i)
             printf("waves/SIMD=%d %-20s %.3f G wave-instr/s/SIMD  (%.2f cycles @2.1GHz)\n", w, names[i], r[i], 2.1 / r[i]);
     }
     return 0;

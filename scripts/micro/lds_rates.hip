@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(512) k(float *out, int iters, int lane_stride_
         else if (OP == 1)
             asm volatile(".rept 8\n ds_write_b64 %0, v[100:101]\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101");
         else if (OP == 2)
-            asm volatile(".rept 8\n ds_write2_b64 %0, v[100:101], v[102:103] offset0:0 offset1:1\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101", "v102", "v103");
+            asm volatile(".rept 8\n ds_write2_b64 %0, v[100:101], v[102:103] offset0:0 offset1:65\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101", "v102", "v103");
         else if (OP == 3)
             asm volatile(".rept 8\n ds_write_b32 %0, v100\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100");
         else if (OP == 4)
@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(512) k(float *out, int iters, int lane_stride_
         else if (OP == 5)
             asm volatile(".rept 8\n ds_read_b64 v[100:101], %0\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101");
         else if (OP == 6)
-            asm volatile(".rept 8\n ds_read2_b64 v[100:103], %0 offset0:0 offset1:1\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101", "v102", "v103");
+            asm volatile(".rept 8\n ds_read2_b64 v[100:103], %0 offset0:0 offset1:65\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100", "v101", "v102", "v103");
         else if (OP == 7)
             asm volatile(".rept 8\n ds_read_b32 v100, %0\n .endr\n s_waitcnt lgkmcnt(0)" ::"v"(addr) : "memory", "v100");
     }
@@ -63,7 +63,7 @@ int main()
     const int iters = 20000;
     const char *names[] = {"ds_write_b128", "ds_write_b64", "ds_write2_b64", "ds_write_b32",
                            "ds_read_b128", "ds_read_b64", "ds_read2_b64", "ds_read_b32"};
-    const int strides[] = {16, 8, 16, 4, 16, 8, 16, 4};
+    const int strides[] = {16, 8, 8, 4, 16, 8, 8, 4};
     for (int waves : {1, 8}) {
         double r[8] = {run<0>(iters, strides[0], waves), run<1>(iters, strides[1], waves), run<2>(iters, strides[2], waves),
                        run<3>(iters, strides[3], waves), run<4>(iters, strides[4], waves), run<5>(iters, strides[5], waves),
