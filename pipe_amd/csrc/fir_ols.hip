@@ -40,7 +40,7 @@ namespace {
 
 constexpr int kM = 1024;         // FFT size
 constexpr int kVecWaves = 16;    // waves per workgroup (= per CU) of the even-channel kernels: 4 per SIMD
-constexpr int kEx = 1088;        // complex elements per wave-private exchange buffer
+constexpr int kEx = 1040;        // complex elements per wave-private exchange buffer (65 x 16)
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
 struct cd {
@@ -172,6 +172,53 @@ __device__ __forceinline__ void apply_powers(cd (&v)[16], const cd w)
     v[15] = cmul(v[15], cmul(b, w3));
 }
 
+// X2 without LDS.  Before: lane = k2 + 16*a (a = the 16-lane row), register d = 4i + j.  The last
+// radix-4 step runs over a, so a has to come into registers: for every i the 4x4 block
+// (row a) x (register j) is transposed with the cross-row swap instructions of gfx950 --
+// v_permlane32_swap (rows {0,1} <-> {2,3} between two registers) then v_permlane16_swap (even <->
+// odd rows) -- 64 32-bit swaps for the 16 complex registers.  After: lane = k2 + 16*j, register
+// 4i + a.  The transpose is two involutions, so the way back applies them in reverse order.
+__device__ __forceinline__ void swap_rows(cd &x, cd &y, bool by32)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u xr = __builtin_bit_cast(v2u, x.re), xi = __builtin_bit_cast(v2u, x.im);
+    v2u yr = __builtin_bit_cast(v2u, y.re), yi = __builtin_bit_cast(v2u, y.im);
+#define PH_SWAP(A, B)                                                                          \
+    do {                                                                                       \
+        const auto r_ = by32 ? __builtin_amdgcn_permlane32_swap((A), (B), false, false)        \
+                             : __builtin_amdgcn_permlane16_swap((A), (B), false, false);       \
+        (A) = r_[0];                                                                           \
+        (B) = r_[1];                                                                           \
+    } while (0)
+    PH_SWAP(xr[0], yr[0]);
+    PH_SWAP(xr[1], yr[1]);
+    PH_SWAP(xi[0], yi[0]);
+    PH_SWAP(xi[1], yi[1]);
+#undef PH_SWAP
+    x.re = __builtin_bit_cast(double, xr);
+    x.im = __builtin_bit_cast(double, xi);
+    y.re = __builtin_bit_cast(double, yr);
+    y.im = __builtin_bit_cast(double, yi);
+}
+template <bool FWD>
+__device__ __forceinline__ void rows_to_regs(cd (&v)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (FWD) {
+            swap_rows(v[4 * i + 0], v[4 * i + 2], true);
+            swap_rows(v[4 * i + 1], v[4 * i + 3], true);
+            swap_rows(v[4 * i + 0], v[4 * i + 1], false);
+            swap_rows(v[4 * i + 2], v[4 * i + 3], false);
+        } else {
+            swap_rows(v[4 * i + 0], v[4 * i + 1], false);
+            swap_rows(v[4 * i + 2], v[4 * i + 3], false);
+            swap_rows(v[4 * i + 0], v[4 * i + 2], true);
+            swap_rows(v[4 * i + 1], v[4 * i + 3], true);
+        }
+    }
+}
+
 template <typename T>
 struct Pair;
 template <>
@@ -241,7 +288,6 @@ __device__ __forceinline__ void wave_fence()
 // (strides are odd so that the 16-lane groups of ds_read2_b64 / ds_write_b64 fall on 16 distinct
 // 8-byte slots)
 __device__ __forceinline__ int ex1_addr(int n1, int k2) { return 65 * k2 + n1; }
-__device__ __forceinline__ int ex2_addr(int a, int d, int k2) { return 272 * a + 17 * k2 + d; }
 
 // VEC: the channel count is even, so a channel pair is one naturally aligned 8/16-byte
 // element: window loads and result stores move whole pairs, and the next item's window is
@@ -273,7 +319,6 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     // lane roles
     const int n1 = lane;                        // L0
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
-    const int dl = lane & 15, kkl = lane >> 4;  // L2: d = lane&15, k2 = kk + 4q
     const int64_t last = a.frames - 1;
     // per-lane twiddle seeds: W1024^n1 (step B) and W64^a (step C2)
     const double2 s1 = tw1_g[64 + n1];
@@ -374,8 +419,6 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     };
     auto x1_lane = [&](int r) { return ex1_addr(n1, r); };                     // (lane n1, reg k2)
     auto x1_grp = [&](int r) { return ex1_addr(al + 4 * r, k2l); };            // (lane k2 + 16a, reg b)
-    auto x2_grp = [&](int r) { return ex2_addr(al, r, k2l); };                 // (lane k2 + 16a, reg d)
-    auto x2_fin = [&](int r) { return ex2_addr(r & 3, dl, kkl + 4 * (r >> 2)); };  // (lane d + 16kk, reg 4q + a)
 
     bool have_pf = false;
     if (PREFETCH && wave_global < a.nitems && interior(cur)) {
@@ -441,7 +484,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         dft16<-1>(v);    // C1: over b -> d
         apply_powers(v, wC);       // C2: W64^(a*d)
         // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
-        exchange(v, x2_grp, x2_fin);
+        rows_to_regs<true>(v);
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
             dft4<-1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -457,7 +500,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        exchange(v, x2_fin, x2_grp);
+        rows_to_regs<false>(v);
         apply_powers(v, wCc);
         dft16<+1>(v);    // over d -> b
         exchange(v, x1_grp, x1_lane);
@@ -518,7 +561,7 @@ bool Plan::supports(int ntaps, int channels)
 static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
 {
     // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M), laid out as the kernel holds the
-    // spectrum: entry (r = 4q + c, lane) is frequency 256c + 16(lane & 15) + (lane >> 4) + 4q
+    // spectrum: entry (r = 4i + c, lane) is frequency 256c + 64i + lane
     std::vector<double> hr(kM), hi(kM);
     for (int k = 0; k < kM; ++k) {
         long double sr = 0, si = 0;
@@ -534,8 +577,8 @@ static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
     out->assign(2 * 16 * 64, 0.0);
     for (int r = 0; r < 16; ++r)
         for (int lane = 0; lane < 64; ++lane) {
-            const int q = r >> 2, c = r & 3;
-            const int k = 256 * c + 16 * (lane & 15) + (lane >> 4) + 4 * q;
+            const int i = r >> 2, c = r & 3;
+            const int k = 256 * c + 64 * i + lane;
             (*out)[2 * (r * 64 + lane)] = hr[k];
             (*out)[2 * (r * 64 + lane) + 1] = hi[k];
         }
