@@ -40,6 +40,7 @@ namespace {
 
 constexpr int kM = 1024;         // FFT size
 constexpr int kVecWaves = 16;    // waves per workgroup (= per CU) of the even-channel kernels: 4 per SIMD
+constexpr int kHalf = 513;        // H[0..512]; padded to 514 entries in LDS for alignment of what follows
 constexpr int kEx = 1040;        // complex elements per wave-private exchange buffer (65 x 16)
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
@@ -144,32 +145,34 @@ __device__ __forceinline__ void dft16(cd (&v)[16])
         }
 }
 
-// v[k] *= w^k for k = 1..15 from the one per-lane constant w (|w| = 1): no twiddle
-// table and no LDS traffic.  Powers are built in groups of four off w, w^2, w^3 so
-// that at most five of them are live at once (register pressure), and no power is
-// more than five complex multiplications away from w (rounding error).
-__device__ __forceinline__ void apply_powers(cd (&v)[16], const cd w)
+// v[k] *= t[k * stride] (CONJ: its conjugate) for k = 1..15, t a row set of an LDS twiddle
+// table (exactly rounded entries: no power chains).  The reads run G entries ahead of their
+// use and the scheduler may not move them further up: fifteen in flight would cost 60 VGPRs and
+// with them the fourth wave per SIMD.
+template <bool CONJ>
+__device__ __forceinline__ void twiddle(cd (&v)[16], const double2 *__restrict__ t, int stride)
 {
-    const cd w2 = cmul(w, w);
-    const cd w3 = cmul(w2, w);
-    v[1] = cmul(v[1], w);
-    v[2] = cmul(v[2], w2);
-    v[3] = cmul(v[3], w3);
-    cd b = cmul(w2, w2);  // w^4
-    v[4] = cmul(v[4], b);
-    v[5] = cmul(v[5], cmul(b, w));
-    v[6] = cmul(v[6], cmul(b, w2));
-    v[7] = cmul(v[7], cmul(b, w3));
-    b = cmul(b, b);  // w^8
-    v[8] = cmul(v[8], b);
-    v[9] = cmul(v[9], cmul(b, w));
-    v[10] = cmul(v[10], cmul(b, w2));
-    v[11] = cmul(v[11], cmul(b, w3));
-    b = cmul(b, cmul(w2, w2));  // w^12
-    v[12] = cmul(v[12], b);
-    v[13] = cmul(v[13], cmul(b, w));
-    v[14] = cmul(v[14], cmul(b, w2));
-    v[15] = cmul(v[15], cmul(b, w3));
+    constexpr int G = 5;
+    double2 w[2][G];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        w[0][j] = t[(1 + j) * stride];
+#pragma unroll
+    for (int g = 0; g < 15 / G; ++g) {
+        if (g + 1 < 15 / G) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                w[(g + 1) & 1][j] = t[(1 + G * (g + 1) + j) * stride];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int k = 1 + G * g + j;
+            const cd ww{w[g & 1][j].x, w[g & 1][j].y};
+            v[k] = CONJ ? cmulc(v[k], ww) : cmul(v[k], ww);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // X2 without LDS.  Before: lane = k2 + 16*a (a = the 16-lane row), register d = 4i + j.  The last
@@ -302,13 +305,21 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                const double2 *__restrict__ tw2_g, const double2 *__restrict__ hperm_g, const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double2 *hperm = reinterpret_cast<double2 *>(smem_raw);  // [16][64] tap spectrum, kernel layout
+    // LDS: tap spectrum H[0..512] (the other half is its conjugate mirror: real taps), the
+    // twiddle tables W1024^(n1*k2) [15][64] and W64^(a*d) [4][16], then the exchange planes
+    double2 *hspec = reinterpret_cast<double2 *>(smem_raw);
+    double2 *tw1s = hspec + kHalf + 1;
+    double2 *tw2s = tw1s + 15 * 64;
     constexpr bool SPLIT = WAVES > 8;
     constexpr bool PREFETCH = WAVES <= 8;
-    double2 *exbase = hperm + 16 * 64;                       // [WAVES][kEx] wave-private exchange
+    double2 *exbase = tw2s + 4 * 16;                         // [WAVES][kEx] wave-private exchange
 
-    for (int i = threadIdx.x; i < 16 * 64; i += WAVES * 64)
-        hperm[i] = hperm_g[i];
+    for (int i = threadIdx.x; i < kHalf; i += WAVES * 64)
+        hspec[i] = hperm_g[i];
+    for (int i = threadIdx.x; i < 15 * 64; i += WAVES * 64)
+        tw1s[i] = tw1_g[64 + i];
+    if (threadIdx.x < 64)
+        tw2s[threadIdx.x] = tw2_g[threadIdx.x];
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
@@ -321,10 +332,14 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
     const int64_t last = a.frames - 1;
     // per-lane twiddle seeds: W1024^n1 (step B) and W64^a (step C2)
-    const double2 s1 = tw1_g[64 + n1];
-    const double2 s2 = tw2_g[al * 16 + 1];
-    cd wB{s1.x, s1.y};
-    cd wC{s2.x, s2.y};
+    // twiddle rows: step B reads tw1s[(k2-1)*64 + n1] (consecutive lanes, consecutive slots),
+    // step C2 reads tw2s[a*16 + d] (one slot per 16-lane row: a broadcast)
+    const double2 *__restrict__ twB = tw1s + n1 - 64;  // indexed with k2*64
+    const double2 *__restrict__ twC = tw2s + al * 16;
+    // spectrum entry of register r = 4i + c is frequency k = 256c + 64i + lane; for c >= 2 it is
+    // read as conj(H[1024 - k])
+    const double2 *__restrict__ hlo = hspec + lane;
+    const double2 *__restrict__ hhi = hspec - lane;  // indexed with 1024 - 256c - 64i
 
     using In2 = typename Pair<TIn>::type;
     // Item coordinates are wave-uniform and live in SGPRs: (Line, tile, channel pair), channel
@@ -428,8 +443,6 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     for (int64_t item = wave_global; item < a.nitems; item += wave_stride) {
         // the seeds are loop-invariant; without this the compiler hoists all 60 of their
         // powers out of the item loop and spills them
-        asm volatile("" : "+v"(wB.re), "+v"(wB.im), "+v"(wC.re), "+v"(wC.im));
-        const cd wBc{wB.re, -wB.im}, wCc{wC.re, -wC.im};
         const int line = cur.line, c0 = cur.pair * 2;
         const bool two = c0 + 1 < a.C;
         const int64_t t0 = (int64_t)cur.tile * a.L, fr0 = t0 - a.H;
@@ -478,22 +491,28 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 
         // ---- forward transform -------------------------------------------------
         dft16<-1>(v);    // A: over n2 -> k2
-        apply_powers(v, wB);       // B: W1024^(n1*k2)
+        twiddle<false>(v, twB, 64);  // B: W1024^(n1*k2)
         // X1: (lane n1, reg k2) -> (lane k2 + 16a, reg b) holding element (a + 4b, k2)
         exchange(v, x1_lane, x1_grp);
         dft16<-1>(v);    // C1: over b -> d
-        apply_powers(v, wC);       // C2: W64^(a*d)
+        twiddle<false>(v, twC, 1);   // C2: W64^(a*d)
         // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
         rows_to_regs<true>(v);
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
             dft4<-1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 
-        // ---- spectrum of the taps (pre-permuted to this layout, scaled by 1/M) --
+        // ---- spectrum of the taps (scaled by 1/M) -------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const double2 h = hperm[r * 64 + lane];
-            v[r] = cmul(v[r], cd{h.x, h.y});
+            const int i = r >> 2, c = r & 3;
+            if (c < 2) {
+                const double2 h = hlo[256 * c + 64 * i];
+                v[r] = cmul(v[r], cd{h.x, h.y});
+            } else {
+                const double2 h = hhi[1024 - 256 * c - 64 * i];
+                v[r] = cmulc(v[r], cd{h.x, h.y});
+            }
         }
 
         // ---- inverse transform: the same steps backwards, conjugate twiddles -----
@@ -501,10 +520,10 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         for (int q = 0; q < 4; ++q)
             dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         rows_to_regs<false>(v);
-        apply_powers(v, wCc);
+        twiddle<true>(v, twC, 1);
         dft16<+1>(v);    // over d -> b
         exchange(v, x1_grp, x1_lane);
-        apply_powers(v, wBc);
+        twiddle<true>(v, twB, 64);
         dft16<+1>(v);    // over k2 -> n2 : v[r] = y_circ[n1 + 64 r]
 
         // ---- store the valid part: window index i >= H is frame t0 + i - H ------
@@ -560,10 +579,10 @@ bool Plan::supports(int ntaps, int channels)
 
 static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
 {
-    // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M), laid out as the kernel holds the
-    // spectrum: entry (r = 4i + c, lane) is frequency 256c + 64i + lane
-    std::vector<double> hr(kM), hi(kM);
-    for (int k = 0; k < kM; ++k) {
+    // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2; the kernel takes the upper
+    // half from H[M - k] = conj(H[k]) (real taps)
+    out->assign(2 * (kHalf + 1), 0.0);
+    for (int k = 0; k < kHalf; ++k) {
         long double sr = 0, si = 0;
         for (int n = 0; n < N; ++n) {
             const int e = (int)(((int64_t)n * k) % kM);
@@ -571,17 +590,9 @@ static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
             sr += (long double)taps[n] * cosl(ang);
             si += (long double)taps[n] * sinl(ang);
         }
-        hr[k] = (double)(sr / kM);
-        hi[k] = (double)(si / kM);
+        (*out)[2 * k] = (double)(sr / kM);
+        (*out)[2 * k + 1] = (double)(si / kM);
     }
-    out->assign(2 * 16 * 64, 0.0);
-    for (int r = 0; r < 16; ++r)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int i = r >> 2, c = r & 3;
-            const int k = 256 * c + 64 * i + lane;
-            (*out)[2 * (r * 64 + lane)] = hr[k];
-            (*out)[2 * (r * 64 + lane) + 1] = hi[k];
-        }
 }
 
 int Plan::init(int device, const double *taps, int ntaps)
@@ -605,8 +616,8 @@ int Plan::init(int device, const double *taps, int ntaps)
         }
     PH_TRY(impl_->tw1.alloc(sizeof(double) * t1.size()));
     PH_TRY(impl_->tw2.alloc(sizeof(double) * t2.size()));
-    PH_TRY(impl_->hperm[0].alloc(sizeof(double) * 2 * 16 * 64));
-    PH_TRY(impl_->hperm[1].alloc(sizeof(double) * 2 * 16 * 64));
+    PH_TRY(impl_->hperm[0].alloc(sizeof(double) * 2 * (kHalf + 1)));
+    PH_TRY(impl_->hperm[1].alloc(sizeof(double) * 2 * (kHalf + 1)));
     PH_HIP(hipMemcpy(impl_->tw1.p, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
     PH_HIP(hipMemcpy(impl_->tw2.p, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
     return set_taps(taps);
@@ -633,7 +644,7 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
                       hipStream_t s)
 {
     auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
-    const size_t lds = sizeof(double2) * (16 * 64) + (WAVES > 8 ? sizeof(double) : sizeof(double2)) * (size_t)kEx * WAVES;
+    const size_t lds = sizeof(double2) * (kHalf + 1 + 15 * 64 + 4 * 16) + (WAVES > 8 ? sizeof(double) : sizeof(double2)) * (size_t)kEx * WAVES;
     if (lds > 64 * 1024)
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
