@@ -51,6 +51,28 @@ int KernelTimer::begin(hipStream_t s)
     return PIPE_HIP_OK;
 }
 
+int KernelTimer::pair(hipEvent_t *a, hipEvent_t *b)
+{
+    *a = nullptr;
+    *b = nullptr;
+    if (!enabled_)
+        return PIPE_HIP_OK;
+    if (used_ == ring_.size()) {
+        if (ring_.size() >= 1024) {
+            PH_TRY(drain());
+        } else {
+            Pair p{};
+            PH_HIP(hipEventCreate(&p.a));
+            PH_HIP(hipEventCreate(&p.b));
+            ring_.push_back(p);
+        }
+    }
+    *a = ring_[used_].a;
+    *b = ring_[used_].b;
+    used_ += 1;
+    return PIPE_HIP_OK;
+}
+
 int KernelTimer::end(hipStream_t s)
 {
     if (!enabled_ || !open_)

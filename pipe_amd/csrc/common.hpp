@@ -95,6 +95,11 @@ public:
     bool enabled() const { return enabled_; }
     int begin(hipStream_t s);
     int end(hipStream_t s);
+    // events for hipExtLaunchKernelGGL: they are attached to the kernel's own dispatch, so
+    // their difference is the kernel's execution time (what rocprofv3 reports), without the
+    // marker packets and dispatch gap that begin()/end() around a launch include.  Both are
+    // nullptr when profiling is off.
+    int pair(hipEvent_t *a, hipEvent_t *b);
     int collect(double *total_ms, int64_t *launches, bool reset);
 
 private:

@@ -27,6 +27,8 @@
 // 8 B of HBM traffic): DESIGN.md "Kernels and their rooflines".
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "fir_ols.hpp"
 
@@ -456,10 +458,8 @@ public:
         // direct form (bit-exact).
         if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
             ols_->items(frames, cfg.channels, cfg.lines) >= ols_min_items()) {
-            PH_TRY(timer.begin(s));
             PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, frames, cfg.channels, cfg.lines, s,
-                             &last_kernel));
-            PH_TRY(timer.end(s));
+                             &last_kernel, &timer));
             return update_history(d_in, in_dtype, hist, frames, s);
         }
         Geometry g;
@@ -488,9 +488,7 @@ public:
         a.out_off = (int)g.out_off;
         a.out_slab = g.out_slab;
         a.taps_off = (int)g.taps_off;
-        PH_TRY(timer.begin(s));
         PH_TRY(launch(g, in_dtype, out_dtype, d_in, d_out, hist, taps, a, s));
-        PH_TRY(timer.end(s));
         return update_history(d_in, in_dtype, hist, frames, s);
     }
 
@@ -597,8 +595,10 @@ private:
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
         const dim3 grid = persistent_grid(reinterpret_cast<const void *>(kfn), g);                   \
-        hipLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, static_cast<const TI *>(d_in),      \
-                           static_cast<TO *>(d_out), hist, taps, a);                                 \
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;                                                   \
+        PH_TRY(timer.pair(&ev_a, &ev_b));                                                            \
+        hipExtLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, ev_a, ev_b, 0,                    \
+                              static_cast<const TI *>(d_in), static_cast<TO *>(d_out), hist, taps, a); \
         last_kernel = NAME;                                                                          \
     } while (0)
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)

@@ -31,6 +31,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "fir_ols.hpp"
 
@@ -352,8 +354,14 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     // are dealt block after block -- so when the items do not divide evenly by the resident
     // waves, the waves with one item more are spread over all CUs (and SIMDs) instead of filling
     // the first blocks
-    const int64_t wave_global = (int64_t)(wave_u / a.group) * ((int64_t)gridDim.x * a.group) +
-                                (int64_t)blockIdx.x * a.group + wave_u % a.group;
+    // Blocks are dealt to the 8 XCDs round robin (block b runs on XCD b % 8) and each XCD has its
+    // own L2: neighbouring tiles share H of their 1024 frames, so consecutive item groups go to
+    // blocks of the SAME XCD (xb = the block's rank in XCD-major order) and the overlap is read
+    // from HBM once.
+    const int nb = (int)gridDim.x;
+    const int xb = nb % 8 == 0 ? ((int)blockIdx.x % 8) * (nb / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int64_t wave_global = (int64_t)(wave_u / a.group) * ((int64_t)nb * a.group) +
+                                (int64_t)xb * a.group + wave_u % a.group;
     const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
     struct Item {
         int line, tile, pair;
@@ -641,7 +649,7 @@ int64_t Plan::items(int64_t frames, int channels, int lines) const
 
 template <typename TIn, typename TOut, int WAVES, bool VEC>
 static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, Args a,
-                      hipStream_t s)
+                      hipStream_t s, KernelTimer *timer)
 {
     auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
     const size_t lds = sizeof(double2) * (kHalf + 1 + 15 * 64 + 4 * 16) + (WAVES > 8 ? sizeof(double) : sizeof(double2)) * (size_t)kEx * WAVES;
@@ -666,7 +674,10 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
     a.d_pair = (int)(stride % a.pairs);
     a.d_tile = (int)((stride / a.pairs) % a.tiles_per_line);
     a.d_line = (int)(stride / a.pairs / a.tiles_per_line);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, s, static_cast<const TIn *>(d_in),
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (timer)
+        PH_TRY(timer->pair(&ev_a, &ev_b));
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
                        static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw1.p),
                        static_cast<const double2 *>(I.tw2.p), static_cast<const double2 *>(I.hperm[I.cur].p), a);
     PH_HIP(hipGetLastError());
@@ -674,7 +685,7 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
 }
 
 int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, int64_t frames,
-              int channels, int lines, hipStream_t s, const char **kernel_name)
+              int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {
     Args a{};
     a.frames = frames;
@@ -693,27 +704,27 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32>";
         if (vec)
-            return launch_ols<float, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
-        return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<float, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
+        return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f64,f32>";
         if (vec)
-            return launch_ols<double, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
-        return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<double, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
+        return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     // float64 output: only as an intermediate of a chain that ends in float32
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f32,f64>";
         if (vec)
-            return launch_ols<float, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
-        return launch_ols<float, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<float, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
+        return launch_ols<float, double, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f64,f64>";
         if (vec)
-            return launch_ols<double, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s);
-        return launch_ols<double, double, 8, false>(*impl_, d_in, d_out, hist, a, s);
+            return launch_ols<double, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
+        return launch_ols<double, double, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     return PIPE_HIP_EINVAL;
 }
