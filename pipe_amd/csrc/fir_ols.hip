@@ -2,8 +2,8 @@
 //
 // Why: the direct form costs 2*N f64 flop per scalar sample and is pinned at the
 // f64 VALU roof (~15 % of the HBM roofline at N = 256).  Overlap-save
-// with a 1024-point float64 FFT costs ~50 DP instructions per sample instead of
-// 256 and moves the kernel towards the memory roof.
+// with a 1024-point float64 FFT costs ~0.7 DP instructions per sample and lane (1064 per
+// 1538-sample item) instead of 256 FMAs and moves the kernel towards the memory roof.
 //
 // Numerics: everything is float64.  Two real channels ride one complex sequence
 // (z = ch0 + i*ch1; the taps are real, so Re/Im of the filtered sequence are the
@@ -17,16 +17,16 @@
 // Mapping: ONE WAVE = one 1024-point complex FFT, held as 16 complex values per
 // lane.  1024 = 16 x 16 x 4:
 //     A  : 16-point DFT in registers over n2           (n = n1 + 64*n2, lane = n1)
-//     B  : twiddle W1024^(n1*k2)        (powers of one per-lane register constant)
-//     X1 : wave-private LDS exchange of complex values (16 B, strides 65 / 1)
+//     B  : twiddle W1024^(n1*k2)                   (LDS table, exactly rounded entries)
+//     X1 : wave-private LDS exchange, stride 65    (re and im through one float64 plane)
 //     C1 : 16-point DFT in registers over b             (n1 = a + 4*b)
-//     C2 : twiddle W64^(a*d)
-//     X2 : wave-private LDS exchange (strides 272 / 17 / 1)
+//     C2 : twiddle W64^(a*d)                                            (LDS table)
+//     X2 : 4x4 (16-lane row a) x (register) transposes with v_permlane32/16_swap: no LDS
 //     C3 : four 4-point DFTs in registers
-// then the spectrum is multiplied by the (pre-permuted, pre-scaled) tap spectrum
-// and the same steps run backwards with conjugate twiddles, ending in natural
-// order, lane n1 holding y[n1 + 64*n2].  No workgroup barrier is needed after
-// the tables are loaded; waves walk (Line, channel pair, tile) items on their own.
+// then the spectrum is multiplied by the tap spectrum (LDS, H[0..512] + conjugate mirror,
+// pre-scaled by 1/M) and the same steps run backwards with conjugate twiddles, ending in
+// natural order, lane n1 holding y[n1 + 64*n2].  No workgroup barrier is needed after the
+// tables are loaded; waves walk (Line, channel pair, tile) items on their own, 16 per CU.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -504,7 +504,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         exchange(v, x1_lane, x1_grp);
         dft16<-1>(v);    // C1: over b -> d
         twiddle<false>(v, twC, 1);   // C2: W64^(a*d)
-        // X2: (lane k2 + 16a, reg d) -> (lane d + 16kk, reg 4q + a) holding (a, d, kk + 4q)
+        // X2: (lane k2 + 16a, reg d = 4i + j) -> (lane k2 + 16j, reg 4i + a), in registers
         rows_to_regs<true>(v);
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
