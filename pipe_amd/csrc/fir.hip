@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
+#include "fir_hist.hpp"
 #include "fir_ols.hpp"
 
 namespace pipehip {
@@ -65,6 +66,7 @@ struct FirArgs {
     int out_off;          // byte offset of the wave-private output slabs in LDS
     int out_slab;         // elements per slab (padded)
     int taps_off;         // byte offset of the LDS copy of the taps
+    double *hist_new;     // the other half of the history double buffer (written by this launch)
 };
 
 // Taps are wave-uniform and immutable during a launch: reading them through the
@@ -127,6 +129,8 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *xs = reinterpret_cast<double *>(smem_raw);
     constexpr int kStep = R > 1 ? R + 1 : 1;
+
+    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
 
     // staging map: lane -> (column tx = channel, row ty = frame) by shifts
     const int tx = threadIdx.x & ((1 << a.cx_log) - 1);
@@ -334,27 +338,6 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     }
 }
 
-// new history = last H frames of (old history ++ this call's input)
-template <typename TIn>
-__global__ void fir_hist_update_kernel(const TIn *__restrict__ in, const double *__restrict__ hist_old,
-                                       double *__restrict__ hist_new, int64_t frames,
-                                       int64_t line_stride, int H, int C)
-{
-    const int line = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * C)
-        return;
-    const int j = i / C;
-    const int c = i - j * C;
-    const int64_t s = frames - H + j;
-    double v;
-    if (s >= 0)
-        v = (double)in[(int64_t)line * line_stride + s * C + c];
-    else
-        v = hist_old[((int64_t)line * H + (s + H)) * C + c];
-    hist_new[((int64_t)line * H + j) * C + c] = v;
-}
-
 struct Geometry {
     int R, CG, ngroups, cgp, lpc_log, cx_log, TF, HP, plane, rows, prefetch, out_slab;
     size_t out_off, taps_off, lds;
@@ -458,9 +441,9 @@ public:
         // direct form (bit-exact).
         if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
             ols_->items(frames, cfg.channels, cfg.lines) >= ols_min_items()) {
-            PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, frames, cfg.channels, cfg.lines, s,
-                             &last_kernel, &timer));
-            return update_history(d_in, in_dtype, hist, frames, s);
+            PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, hist_next(), frames, cfg.channels,
+                             cfg.lines, s, &last_kernel, &timer));
+            return flip_history();
         }
         Geometry g;
         if (!choose(frames, &g))
@@ -488,8 +471,9 @@ public:
         a.out_off = (int)g.out_off;
         a.out_slab = g.out_slab;
         a.taps_off = (int)g.taps_off;
+        a.hist_new = hist_next();
         PH_TRY(launch(g, in_dtype, out_dtype, d_in, d_out, hist, taps, a, s));
-        return update_history(d_in, in_dtype, hist, frames, s);
+        return flip_history();
     }
 
 private:
@@ -502,24 +486,12 @@ private:
     }
 
     // new history = last N-1 frames of (old history ++ this call's input)
-    int update_history(const void *d_in, int in_dtype, const double *hist, int64_t frames, hipStream_t s)
+    // the launch just queued wrote the other half of the history double buffer
+    double *hist_next() const { return static_cast<double *>(hist_[cur_hist_ ^ 1].p); }
+    int flip_history()
     {
-        if (H_ > 0) {
-            const int n = H_ * cfg.channels;
-            const dim3 hg((unsigned)((n + 255) / 256), (unsigned)cfg.lines);
-            double *hn = static_cast<double *>(hist_[cur_hist_ ^ 1].p);
-            const int64_t line_stride = frames * cfg.channels;
-            if (in_dtype == PIPE_HIP_F32)
-                hipLaunchKernelGGL(fir_hist_update_kernel<float>, hg, dim3(256), 0, s,
-                                   static_cast<const float *>(d_in), hist, hn, frames, line_stride, H_,
-                                   cfg.channels);
-            else
-                hipLaunchKernelGGL(fir_hist_update_kernel<double>, hg, dim3(256), 0, s,
-                                   static_cast<const double *>(d_in), hist, hn, frames, line_stride, H_,
-                                   cfg.channels);
-            PH_HIP(hipGetLastError());
+        if (H_ > 0)
             cur_hist_ ^= 1;
-        }
         return PIPE_HIP_OK;
     }
 

@@ -34,6 +34,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
+#include "fir_hist.hpp"
 #include "fir_ols.hpp"
 
 namespace pipehip {
@@ -277,6 +278,7 @@ struct Args {
     int64_t nitems;       // lines * pairs * tiles_per_line
     int d_pair, d_tile, d_line;  // the wave stride of the launch as (pair, tile, Line) digits
     int group;                   // waves of a block that take consecutive items
+    double *hist_new;            // the other half of the history double buffer (written here)
 };
 
 // Lanes of one wave talk through the wave-private buffer.  The hardware keeps a
@@ -316,6 +318,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     constexpr bool PREFETCH = WAVES <= 8;
     double2 *exbase = tw2s + 4 * 16;                         // [WAVES][kEx] wave-private exchange
 
+    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < kHalf; i += WAVES * 64)
         hspec[i] = hperm_g[i];
     for (int i = threadIdx.x; i < 15 * 64; i += WAVES * 64)
@@ -684,11 +687,13 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
     return PIPE_HIP_OK;
 }
 
-int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, int64_t frames,
+int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, double *hist_new,
+              int64_t frames,
               int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {
     Args a{};
     a.frames = frames;
+    a.hist_new = hist_new;
     a.line_stride = frames * channels;
     a.C = channels;
     a.N = impl_->N;
