@@ -32,6 +32,29 @@ class PipeHipError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One process, one HIP runtime.  PyTorch-ROCm ships its own libamdhip64.so; if libpipe_hip.so
+    is loaded first it binds /opt/rocm's copy, torch later brings the other one, and the runtime
+    that initialises second finds no device.  Loading torch's copy first (when torch is installed
+    and not imported yet) makes both resolve to the same library, whichever import order the
+    caller uses -- e.g. build() followed by smoke() in one interpreter."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # fall back to the system runtime; a GPU-less container lands here too
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -40,6 +63,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pipe_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     dp = C.POINTER(C.c_double)
