@@ -203,3 +203,44 @@ def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
                 assert np.array_equal(got[l], want.astype(np.float32))
             else:
                 assert ulp_diff_f32(got[l], want, floor).max() <= 1.0
+
+
+@pytest.mark.parametrize("lines,channels,frames,ntaps", [
+    (1, 2, 769 * 300 + 17, 256),   # 301 tiles: fewer blocks than CUs x 16 waves, ragged last tile
+    (3, 6, 50_000, 100),           # 3 channel pairs: wave groups of 4 > pairs
+    (7, 16, 20_000, 256),          # 8 pairs, several Lines, grid not a multiple of 8 XCDs
+    (37, 2, 9_000, 33),            # many short Lines: most tiles are a Line's first (history) tile
+    (2, 64, 12_345, 512),          # the channel limit and the longest supported filter
+    (5, 5, 7_777, 16),             # odd channel count (scalar-pair path), shortest supported filter
+])
+def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
+    # every (Line, channel pair, tile) item must be produced exactly once whatever the grid,
+    # the wave grouping and the XCD-aware order make of the shape: compare with the direct form
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    rng = np.random.default_rng(1234 + lines * 100 + channels)
+    x = rng.uniform(-1, 1, size=(lines, frames, channels)).astype(np.float32)
+    outs = {}
+    for exact in (False, True):
+        with P.Fir(taps, frames, channels, dtype=np.float32, lines=lines, max_batch=1) as p:
+            p.start()
+            if exact:
+                p.set_exact(True)
+            d_in = torch.from_numpy(x).cuda()
+            half = frames // 3
+            ys = []
+            for a, b in ((0, half), (half, frames)):   # two calls: the history must carry
+                xin = d_in[:, a:b, :].contiguous()
+                y = torch.full_like(xin, float("nan"))
+                p.process_batch(xin, y, b - a)
+                ys.append(y)
+            torch.cuda.synchronize()
+            outs[exact] = (torch.cat(ys, dim=1).cpu().numpy(), p.kernel_name())
+    got, name = outs[False]
+    ref, name2 = outs[True]
+    assert "fir_ols_kernel" in name and "fir_direct_kernel" in name2
+    assert not np.isnan(got).any()
+    floor = 2.0 ** -24 * np.abs(taps).sum()
+    d = ulp_diff_f32(got, ref.astype(np.float64), floor)
+    assert d.max() <= 1.0, float(d.max())
+    assert np.mean(got != ref) < 1e-3
