@@ -232,6 +232,151 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
     }
 }
 
+// LDS-staged form of the exact recurrence.  One workgroup = one Line (x one group of up to 64
+// channels).  The one-lane-per-series kernel above pays a memory round trip per chunk of
+// frames, in series with its dependent fma chain -- over PCIe (zero-copy ProcessFunc form) that
+// is ~2 us per 32 frames.  Here all 256 lanes first copy a block of frames into LDS (coalesced,
+// everything in flight at once, widened to float64), the channels' lanes then run the SAME
+// ordered recurrence out of LDS (reads issued one chunk ahead, ~100 cycles instead of a memory
+// round trip), results go back in place, and all lanes store them coalesced.  Bit-exact like the
+// register form; the state lives in registers across blocks.
+constexpr int kLdsThreads = 256;
+constexpr int kLdsChunk = 16;
+
+struct BiquadLdsArgs {
+    double *state;
+    int64_t frames;
+    int C, S, cgroups;  // channels, sections, channel groups of <= 64 per Line
+    int fb;             // frames per LDS block
+    double gain;
+};
+
+template <typename TIn, typename TOut, int NS, bool GAIN>
+__global__ void __launch_bounds__(kLdsThreads)
+biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadLdsArgs a,
+                  const BiquadCoeffs q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *xs = reinterpret_cast<double *>(smem_raw);  // [fb][cg]
+    const int line = blockIdx.x / a.cgroups;
+    const int c0 = (blockIdx.x - line * a.cgroups) * 64;
+    const int cg = a.C - c0 < 64 ? a.C - c0 : 64;
+    const int tid = threadIdx.x;
+    const bool lane_live = tid < cg;
+    double *__restrict__ st = a.state + ((int64_t)line * a.C + c0 + (lane_live ? tid : 0)) * a.S * 2;
+
+    double s1[kMaxSections], s2[kMaxSections];
+#pragma unroll
+    for (int s = 0; s < kMaxSections; ++s) {
+        s1[s] = 0.0;
+        s2[s] = 0.0;
+        if (lane_live && s < a.S) {
+            s1[s] = st[2 * s];
+            s2[s] = st[2 * s + 1];
+        }
+    }
+    auto step = [&](double x) -> double {
+        double y;
+        if constexpr (NS > 0) {
+            y = biquad_step<NS>(x, s1, s2, q);
+        } else {
+            y = x;
+#pragma unroll
+            for (int s = 0; s < kMaxSections; ++s) {
+                if (s < a.S) {
+                    const double v = __builtin_fma(q.c[s][0], y, s1[s]);
+                    const double t = __builtin_fma(q.c[s][1], y, s2[s]);
+                    s1[s] = __builtin_fma(-q.c[s][3], v, t);
+                    const double u = q.c[s][2] * y;
+                    s2[s] = __builtin_fma(-q.c[s][4], v, u);
+                    y = v;
+                }
+            }
+        }
+        if constexpr (GAIN)
+            y = y * a.gain;
+        return y;
+    };
+
+    const TIn *__restrict__ in = in_base + (int64_t)line * a.frames * a.C;
+    TOut *__restrict__ out = out_base + (int64_t)line * a.frames * a.C;
+    const bool whole = cg == a.C;  // the block is one contiguous run of elements
+    for (int64_t f0 = 0; f0 < a.frames; f0 += a.fb) {
+        const int nb = a.frames - f0 < a.fb ? (int)(a.frames - f0) : a.fb;
+        const int nel = nb * cg;
+        // ---- stage: 8 loads in flight per lane ------------------------------------
+        for (int e0 = tid; e0 < nel; e0 += 8 * kLdsThreads) {
+            TIn v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int e = e0 + u * kLdsThreads;
+                e = e < nel ? e : nel - 1;
+                const int64_t g = whole ? f0 * a.C + e : (f0 + e / cg) * a.C + c0 + e % cg;
+                v[u] = in[g];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kLdsThreads;
+                if (e < nel)
+                    xs[e] = (double)v[u];
+            }
+        }
+        __syncthreads();
+        // ---- the recurrence, out of LDS, in place -----------------------------------
+        if (lane_live) {
+            double *__restrict__ col = xs + tid;
+            const int nch = nb / kLdsChunk;
+            double xa[kLdsChunk], xb[kLdsChunk];
+            if (nch > 0) {
+#pragma unroll
+                for (int u = 0; u < kLdsChunk; ++u)
+                    xa[u] = col[u * cg];
+            }
+            // chunk k is computed while chunk k+1 is being read; the two register sets swap
+            // roles instead of being copied
+            auto run_chunk = [&](double (&x)[kLdsChunk], double (&nx)[kLdsChunk], int k) {
+                double *__restrict__ cur = col + (int64_t)k * kLdsChunk * cg;
+                if (k + 1 < nch) {
+#pragma unroll
+                    for (int u = 0; u < kLdsChunk; ++u)
+                        nx[u] = cur[(kLdsChunk + u) * cg];
+                }
+#pragma unroll
+                for (int u = 0; u < kLdsChunk; ++u)
+                    x[u] = step(x[u]);
+#pragma unroll
+                for (int u = 0; u < kLdsChunk; ++u)
+                    cur[u * cg] = x[u];
+            };
+            int k = 0;
+            for (; k + 2 <= nch; k += 2) {
+                run_chunk(xa, xb, k);
+                run_chunk(xb, xa, k + 1);
+            }
+            if (k < nch)
+                run_chunk(xa, xb, k);
+            for (int n = nch * kLdsChunk; n < nb; ++n)
+                col[n * cg] = step(col[n * cg]);
+        }
+        __syncthreads();
+        // ---- store ------------------------------------------------------------------
+        for (int e = tid; e < nel; e += kLdsThreads) {
+            const int64_t g = whole ? f0 * a.C + e : (f0 + e / cg) * a.C + c0 + e % cg;
+            out[g] = (TOut)xs[e];
+        }
+        __syncthreads();
+    }
+    if (lane_live) {
+#pragma unroll
+        for (int s = 0; s < kMaxSections; ++s) {
+            if (s < a.S) {
+                st[2 * s] = s1[s];
+                st[2 * s + 1] = s2[s];
+            }
+        }
+    }
+}
+
 // pass 2: per series, turn the zero-state end states z_k into the true start states s_k
 // (in place) and leave the state after the last segment in the persistent state array.
 // N = 2S states.  The z_k of kScanChunk segments are fetched together (independent loads), so
@@ -410,6 +555,54 @@ public:
 #undef PH_BQ
 #undef PH_BQ2
 #undef PH_BQ3
+        } else if (use_lds_form()) {
+            BiquadLdsArgs la{};
+            la.state = a.state;
+            la.frames = frames;
+            la.C = cfg.channels;
+            la.S = S_;
+            la.cgroups = (cfg.channels + 63) / 64;
+            la.gain = gain_;
+            const int cg = cfg.channels < 64 ? cfg.channels : 64;
+            // as many frames per block as 60 KB of LDS hold (two workgroups per CU), a multiple
+            // of the chunk, never more than the call
+            int64_t fb = (60 * 1024) / (int64_t)(sizeof(double) * cg);
+            fb = fb / kLdsChunk * kLdsChunk;
+            if (fb > frames)
+                fb = (frames + kLdsChunk - 1) / kLdsChunk * kLdsChunk;
+            la.fb = (int)fb;
+            const size_t lds = sizeof(double) * (size_t)fb * (size_t)cg;
+            const dim3 grid((unsigned)(cfg.lines * la.cgroups));
+#define PH_BQ2(TI, TO, G)                                                                              \
+    do {                                                                                               \
+        if (S_ == 1)                                                                                   \
+            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 1, G>), grid, dim3(kLdsThreads), lds, s,     \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+        else if (S_ == 2)                                                                              \
+            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 2, G>), grid, dim3(kLdsThreads), lds, s,     \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+        else                                                                                           \
+            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 0, G>), grid, dim3(kLdsThreads), lds, s,     \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+    } while (0)
+#define PH_BQ(TI, TO, NAME)            \
+    do {                               \
+        if (has_gain_)                 \
+            PH_BQ2(TI, TO, true);      \
+        else                           \
+            PH_BQ2(TI, TO, false);     \
+        last_kernel = NAME;            \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_BQ(float, float, "biquad_lds_kernel<f32,f32>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_BQ(double, double, "biquad_lds_kernel<f64,f64>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_BQ(float, double, "biquad_lds_kernel<f32,f64>");
+            else
+                PH_BQ(double, float, "biquad_lds_kernel<f64,f32>");
+#undef PH_BQ
+#undef PH_BQ2
         } else {
             const dim3 grid(sblocks);
 #define PH_BQ2(TI, TO, G)                                                                              \
@@ -446,6 +639,17 @@ public:
         PH_HIP(hipGetLastError());
         PH_TRY(timer.end(s));
         return PIPE_HIP_OK;
+    }
+
+    // The LDS-staged exact kernel runs one workgroup per Line: it wins when Lines are few enough
+    // that the register form cannot fill its waves anyway (always the case for the per-buffer
+    // ProcessFunc form); with thousands of series the register form's 64 busy lanes per wave do.
+    bool use_lds_form() const
+    {
+        static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");
+        if (env)
+            return std::atoi(env) != 0;
+        return cfg.lines * ((cfg.channels + 63) / 64) <= 256 && cfg.lines * cfg.channels <= 2048;
     }
 
     void launch_scan(unsigned sblocks, hipStream_t s, const BiquadArgs &a, const BiquadTransition &mlast)
