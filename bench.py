@@ -40,8 +40,8 @@ BYTES_PER_SAMPLE = {"f32": 8, "f64": 16}  # in + out, taps/histo
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--buffers", type=int, default=4096, help="4096-frame buffers per Line per step")
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=2)
