@@ -297,11 +297,11 @@ __device__ __forceinline__ void wave_fence()
 __device__ __forceinline__ int ex1_addr(int n1, int k2) { return 65 * k2 + n1; }
 
 // VEC: the channel count is even, so a channel pair is one naturally aligned 8/16-byte
-// element: window loads and result stores move whole pairs, and the next item's window is
-// prefetched into registers while the current one is transformed.
-// WAVES > 8 (three waves per SIMD): the exchange buffers shrink to one float64 plane per wave
-// (real and imaginary parts go through it one after the other) and the register prefetch of
-// the next window is dropped -- the third wave hides that latency instead.
+// element: window loads and result stores move whole pairs through buffer resources.
+// WAVES = 16 (four waves per SIMD, the even-channel kernels): the exchange buffer is one
+// float64 plane per wave (real and imaginary parts go through it one after the other), and there
+// is no register prefetch of the next window -- the other three waves hide that latency.
+// WAVES = 8 (odd channel counts): complex exchange slabs, next window prefetched into registers.
 template <typename TIn, typename TOut, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64)
 fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
@@ -336,7 +336,6 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const int n1 = lane;                        // L0
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
     const int64_t last = a.frames - 1;
-    // per-lane twiddle seeds: W1024^n1 (step B) and W64^a (step C2)
     // twiddle rows: step B reads tw1s[(k2-1)*64 + n1] (consecutive lanes, consecutive slots),
     // step C2 reads tw2s[a*16 + d] (one slot per 16-lane row: a broadcast)
     const double2 *__restrict__ twB = tw1s + n1 - 64;  // indexed with k2*64
@@ -352,11 +351,11 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     // a workgroup work on them at the same time.  They advance by the launch's wave stride
     // without a division (a.d_pair / a.d_tile / a.d_line are that stride's digits).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // wave w of block b starts at item (w / G)*(blocks*G) + b*G + w % G: groups of G = a.group
+    // wave w of block b starts at item (w / G)*(blocks*G) + xb*G + w % G: groups of G = a.group
     // neighbouring waves take neighbouring items (the channel pairs of one tile), and the groups
     // are dealt block after block -- so when the items do not divide evenly by the resident
     // waves, the waves with one item more are spread over all CUs (and SIMDs) instead of filling
-    // the first blocks
+    // the first blocks.
     // Blocks are dealt to the 8 XCDs round robin (block b runs on XCD b % 8) and each XCD has its
     // own L2: neighbouring tiles share H of their 1024 frames, so consecutive item groups go to
     // blocks of the SAME XCD (xb = the block's rank in XCD-major order) and the overlap is read
