@@ -153,11 +153,11 @@ def main():
     achieved_gbs = samples_per_step_rank * bps / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     # real float64 flops the launched kernel form executes per scalar sample:
     #   direct form      : 2 * taps (ordered fma chain, bit-exact)
-    #   overlap-save FFT : 1284 DP instructions (326 fma) per lane per 1024-point item of
-    #                      (1024 - taps + 1) frames x 2 channels -> ~67 flop/sample at 256 taps
+    #   overlap-save FFT : 1056 DP instructions (208 fma) per lane per 1024-point item of
+    #                      (1024 - taps + 1) frames x 2 channels -> ~53 flop/sample at 256 taps
     is_ols = "ols" in kname
     if is_ols:
-        flop_per_sample = (1284 + 326) * 64 / ((1024 - (N - 1)) * 2.0)
+        flop_per_sample = (1056 + 208) * 64 / ((1024 - (N - 1)) * 2.0)
     else:
         flop_per_sample = 2.0 * N
     flops = flop_per_sample * samples_per_step_rank
