@@ -57,7 +57,10 @@ typedef enum pipe_hip_param {
                                   the oracle) even for float32 results, which otherwise may use the
                                   FIR's overlap-save FFT form / the biquad's time-segmented form
                                   (both <= 1 ulp f32).  float64 buffers always take the exact form.
-                                  On a chain it applies to every stage. */
+                                  On a chain it applies to every stage.  The relaxed forms mix
+                                  the samples of a 1024-frame window / a segment, so a NaN or Inf
+                                  input reaches more outputs than in the ordered form: set this
+                                  for streams that may carry non-finite samples. */
 } pipe_hip_param;
 
 /* Opaque Processor handle: the state a Go closure would capture. */
