@@ -380,3 +380,28 @@ def test_argument_errors():
         with pytest.raises(PipeHipError) as e:
             p.process(np.zeros((513, 2), np.float32))  # in_frames > bufferSize
         assert e.value.status == EINVAL
+
+
+# ------------------------------------------------------------------ non-finite samples
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_exact_forms_treat_non_finite_samples_like_the_oracle(dtype):
+    # NaN / Inf travel through the ordered fma chains exactly as in the oracle: the FIR spreads
+    # them over ntaps outputs of that channel only, the biquad over the rest of the series
+    F, C, N = 2048, 2, 100
+    h = synth.fir_lowpass_taps(N)
+    q = synth.biquad_rbj_lowpass()
+    x = sig(21, F, C, dtype).copy()
+    x[300, 0] = np.nan
+    x[900, 1] = np.inf
+    x[1500, 0] = -np.inf
+    with P.Fir(h, F, C, dtype=dtype) as p:
+        p.start()
+        got = p.process(x)
+    want = expect(O.Fir(h, C).process(x.astype(np.float64)).reshape(F, C), dtype)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isfinite(got[:300]).all() and np.isfinite(got[300 + N:900, 0]).all()
+    with P.Biquad(q, F, C, dtype=dtype) as p:
+        p.start()
+        got = p.process(x)
+    want = expect(O.Biquad(q, C).process(x.astype(np.float64)).reshape(F, C), dtype)
+    assert np.array_equal(got, want, equal_nan=True)
