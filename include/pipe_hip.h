@@ -135,6 +135,12 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
  * Fixed-rate processors only.  Synchronous. */
 int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
                            void *const *outs, int32_t *out_frames);
+/* The same step when every ins[l] / outs[l] was allocated with pipe_hip_host_alloc (pinned,
+ * device-visible -- what a pool built on it hands out, signal.PoolAllocator pipe.go:490-492):
+ * the device gathers the L buffers over PCIe itself and scatters the results back, no host
+ * copy and no staging DMA.  Passing pageable memory here is undefined behaviour. */
+int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
+                                  void *const *outs, int32_t *out_frames);
 /* ProcessFunc for the n-input mix: ins[i] are HOST pointers of `frames` frames. */
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
                          int32_t frames, void *out);

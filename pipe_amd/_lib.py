@@ -87,6 +87,7 @@ def lib():
         "pipe_hip_process": (C.c_int, [vp, vp, i32, vp, i32, C.POINTER(i32)]),
         "pipe_hip_mix_process": (C.c_int, [vp, hp, i32, i32, vp]),
         "pipe_hip_process_lines": (C.c_int, [vp, hp, C.POINTER(i32), hp, C.POINTER(i32)]),
+        "pipe_hip_process_lines_pinned": (C.c_int, [vp, hp, C.POINTER(i32), hp, C.POINTER(i32)]),
         "pipe_hip_submit": (C.c_int, [vp, vp, i32]),
         "pipe_hip_collect": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "pipe_hip_set_param": (C.c_int, [vp, i32, dp, i32]),

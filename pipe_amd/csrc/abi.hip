@@ -472,6 +472,55 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
     return PIPE_HIP_OK;
 }
 
+int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
+                                  void *const *outs, int32_t *out_frames)
+{
+    if (!p || !ins || !in_frames || !outs || !p->fixed_rate() || !p->single_input())
+        return PIPE_HIP_EINVAL;
+    if (p->in_flight)
+        return PIPE_HIP_ESTATE;
+    PH_TRY(p->select_device());
+    PH_TRY(p->ensure_staging());
+    const int L = p->cfg.lines;
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t fb_in = es * (size_t)p->cfg.channels, fb_out = es * (size_t)p->out_channels();
+    if (fb_in % 8 != 0 || fb_out % 8 != 0)  // the row kernels move 8-byte words
+        return pipe_hip_process_lines(p, ins, in_frames, outs, out_frames);
+    int32_t frames = 0;
+    for (int l = 0; l < L; ++l) {
+        if (in_frames[l] < 0 || in_frames[l] > p->cfg.buffer_size || (ins[l] && in_frames[l] > 0 && !outs[l]))
+            return PIPE_HIP_EINVAL;
+        if (ins[l] && in_frames[l] > frames)
+            frames = in_frames[l];
+    }
+    if (out_frames)
+        for (int l = 0; l < L; ++l)
+            out_frames[l] = ins[l] ? in_frames[l] : 0;
+    if (frames == 0)
+        return PIPE_HIP_OK;
+    // tables the kernels read: [L] in pointers, [L] out pointers, [L] in words, [L] out words
+    const size_t tab_bytes = (size_t)L * (2 * sizeof(void *) + 2 * sizeof(int));
+    if (p->line_tab.bytes < tab_bytes)
+        PH_TRY(p->line_tab.alloc(tab_bytes));
+    const void **tin = static_cast<const void **>(p->line_tab.p);
+    void **tout = const_cast<void **>(tin + L);
+    int *win = reinterpret_cast<int *>(tout + L);
+    int *wout = win + L;
+    for (int l = 0; l < L; ++l) {
+        const bool live = ins[l] && in_frames[l] > 0;
+        tin[l] = live ? ins[l] : nullptr;
+        tout[l] = live ? outs[l] : nullptr;
+        win[l] = live ? (int)((size_t)in_frames[l] * fb_in / 8) : 0;
+        wout[l] = live ? (int)((size_t)in_frames[l] * fb_out / 8) : 0;
+    }
+    int64_t produced = frames;
+    PH_TRY(launch_gather_rows(tin, win, p->d_in.p, (int)((size_t)frames * fb_in / 8), L, p->stream));
+    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, frames, p->d_out.p, p->cfg.dtype, frames, &produced, p->stream));
+    PH_TRY(launch_scatter_rows(tout, wout, p->d_out.p, (int)((size_t)frames * fb_out / 8), L, p->stream));
+    PH_HIP(hipStreamSynchronize(p->stream));
+    return PIPE_HIP_OK;
+}
+
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
                          int32_t frames, void *out)
 {

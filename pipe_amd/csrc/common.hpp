@@ -129,6 +129,7 @@ struct pipe_hip_processor {
     pipehip::DevBuf d_in, d_out;
     pipehip::PinnedBuf h_in, h_out;
     void *hd_in = nullptr, *hd_out = nullptr;  // device aliases of h_in / h_out (zero-copy path)
+    pipehip::PinnedBuf line_tab;               // pointer / length tables of process_lines_pinned
     hipEvent_t done = nullptr;
     bool in_flight = false;
     int32_t in_flight_out_frames = 0;
@@ -203,6 +204,8 @@ int mix_run(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, v
             int64_t frames, hipStream_t s);
 
 int launch_synth_fill(void *d_out, int dtype, uint64_t seed, int64_t first, int64_t n, hipStream_t s);
+int launch_gather_rows(const void *const *tab, const int *words, void *dst, int row_words, int lines, hipStream_t s);
+int launch_scatter_rows(void *const *tab, const int *words, const void *src, int row_words, int lines, hipStream_t s);
 
 // chain fusion hooks: true when `p` is a gain stage (its current gain in *g) / a biquad stage
 bool gain_value(const pipe_hip_processor *p, double *g);

@@ -237,6 +237,54 @@ int mix_run(pipe_hip_processor *p, const void *const *d_ins, int32_t n_inputs, v
     return m->run_n(d_ins, n_inputs, d_out, frames, s);
 }
 
+// Rows of L Lines between scattered (pinned host, device-visible) buffers and one packed
+// device block, 8 bytes per lane: the gather / scatter of pipe_hip_process_lines_pinned.
+// tab[l] = buffer of Line l (nullptr: idle slot), words[l] = its length in 8-byte words;
+// a packed row is row_words long, the tail past words[l] is zero-filled on gather.
+__global__ void gather_rows_kernel(const uint64_t *const *__restrict__ tab, const int *__restrict__ words,
+                                   uint64_t *__restrict__ dst, int row_words)
+{
+    const int l = blockIdx.y;
+    const uint64_t *__restrict__ src = tab[l];
+    const int have = src ? words[l] : 0;
+    uint64_t *__restrict__ row = dst + (int64_t)l * row_words;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_words; i += gridDim.x * blockDim.x)
+        row[i] = i < have ? src[i] : 0ull;
+}
+
+__global__ void scatter_rows_kernel(uint64_t *const *__restrict__ tab, const int *__restrict__ words,
+                                    const uint64_t *__restrict__ src, int row_words)
+{
+    const int l = blockIdx.y;
+    uint64_t *__restrict__ dst = tab[l];
+    const int have = dst ? words[l] : 0;
+    const uint64_t *__restrict__ row = src + (int64_t)l * row_words;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < have; i += gridDim.x * blockDim.x)
+        dst[i] = row[i];
+}
+
+int launch_gather_rows(const void *const *tab, const int *words, void *dst, int row_words, int lines, hipStream_t s)
+{
+    if (row_words <= 0 || lines <= 0)
+        return PIPE_HIP_OK;
+    const int bx = (row_words + 4 * kThreads - 1) / (4 * kThreads);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(bx < 64 ? bx : 64), (unsigned)lines), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint64_t *const *>(tab), words, static_cast<uint64_t *>(dst), row_words);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
+int launch_scatter_rows(void *const *tab, const int *words, const void *src, int row_words, int lines, hipStream_t s)
+{
+    if (row_words <= 0 || lines <= 0)
+        return PIPE_HIP_OK;
+    const int bx = (row_words + 4 * kThreads - 1) / (4 * kThreads);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)(bx < 64 ? bx : 64), (unsigned)lines), dim3(kThreads), 0, s,
+                       reinterpret_cast<uint64_t *const *>(tab), words, static_cast<const uint64_t *>(src), row_words);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
 int launch_synth_fill(void *d_out, int dtype, uint64_t seed, int64_t first, int64_t n, hipStream_t s)
 {
     if (n <= 0)

@@ -199,16 +199,22 @@ public:
         out_ptr_.assign(n, nullptr);
         frames_.assign(n, 0);
         written_.assign(n, 0);
+        bool pinned = true;
         for (size_t i = 0; i < n; ++i) {
             if (!ins[i])
                 continue;
             if (outs[i]->Length() < ins[i]->Length())
                 return NewError("batched chain: output buffer shorter than input");
+            pinned = pinned && ins[i]->Pinned() && outs[i]->Pinned();
             in_ptr_[i] = ins[i]->data();
             out_ptr_[i] = outs[i]->data();
             frames_[i] = ins[i]->Length();
         }
-        const int st = pipe_hip_process_lines(h_->get(), in_ptr_.data(), frames_.data(), out_ptr_.data(), written_.data());
+        // pool buffers on pinned memory: the device gathers / scatters them itself
+        const int st = pinned ? pipe_hip_process_lines_pinned(h_->get(), in_ptr_.data(), frames_.data(),
+                                                              out_ptr_.data(), written_.data())
+                              : pipe_hip_process_lines(h_->get(), in_ptr_.data(), frames_.data(), out_ptr_.data(),
+                                                       written_.data());
         if (st != PIPE_HIP_OK)
             return StatusError(st, "process_lines");
         for (size_t i = 0; i < n; ++i)

@@ -39,6 +39,7 @@ class Floating {
 public:
     Floating() = default;
     bool valid() const { return static_cast<bool>(store_); }
+    bool Pinned() const { return store_ && store_->pinned; }  // storage came from the pinned allocator
     int Channels() const { return channels_; }
     int Length() const { return length_; }      // frames
     int Capacity() const { return capacity_; }  // frames
