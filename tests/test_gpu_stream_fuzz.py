@@ -87,3 +87,29 @@ def test_biquad_and_chain_stream_fuzz(seed):
             got = pc.process(x)
             want = O.gain(rb2.process(rf.process(x64)), g).reshape(n, C).astype(dtype)
             assert np.array_equal(got, want), (seed, k, n, "chain")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_resampler_and_mix_stream_fuzz(seed):
+    rng = np.random.default_rng(3000 + seed)
+    C = int(rng.choice([1, 2, 3, 8]))
+    F = int(rng.choice([100, 512, 1024]))
+    up, down = [(160, 147), (147, 160), (3, 2), (2, 3), (1, 4), (5, 1), (7, 7), (48, 441)][seed]
+    T = int(rng.choice([4, 12, 24]))
+    dtype = np.float32 if seed % 2 else np.float64
+    proto = synth.resampler_proto(up, down, T)
+    lens = lengths(rng, F, 10)
+    cap = -(-F * up // down) + 1
+    ref = O.Resampler(proto, T, up, down, C)
+    with P.Resampler(proto, T, up, down, F, C, dtype=dtype) as p, P.Mix(3, F, C, dtype=dtype) as m:
+        p.start()
+        m.start()
+        for k, n in enumerate(lens):
+            x = rng.uniform(-1, 1, size=(n, C)).astype(dtype)
+            got = p.process(x, out_cap_frames=cap)
+            want = ref.process(x.astype(np.float64)).reshape(-1, C).astype(dtype)
+            assert got.shape == want.shape, (seed, k, n)
+            assert np.array_equal(got, want), (seed, k, n)
+            if n:
+                xs = [rng.uniform(-1, 1, size=(n, C)).astype(dtype) for _ in range(3)]
+                assert np.array_equal(m.process(xs), O.mix([a.astype(np.float64) for a in xs]).astype(dtype))
