@@ -68,7 +68,6 @@ __global__ void __launch_bounds__(kThreads) resample_kernel(const ResampleArgs a
 // channels, so every tap is read once per frame and the result leaves as one contiguous
 // C-element vector per lane (coalesced).  Same fma order as the gather kernel: bit-exact.
 constexpr int kOutTile = 1024;
-constexpr int kMaxCh = 8;
 
 struct TiledArgs {
     ResampleArgs r;
