@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--buffers", type=int, default=4096, help="4096-frame buffers per Line per step")
+    ap.add_argument("--buffers", type=int, default=131072,
+                    help="consecutive 4096-frame buffers of the Line resident in HBM per step (default: 4.3 GB in, 4.3 GB out)")
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--taps", type=int, default=256)
@@ -164,8 +165,10 @@ def main():
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        try:  # PMC passes cannot run inside this process: the committed figure, if it is of this workload
+            pmc = json.load(open(pmc_path))
+            if pmc.get("algorithmic_bytes_per_launch") == samples_per_step_rank * bps and is_ols:
+                traffic = pmc.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-env $EXTRA_ENV rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
+env $EXTRA_ENV rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
 pmc() { # name counters...
   local name=$1; shift
   env $EXTRA_ENV rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err

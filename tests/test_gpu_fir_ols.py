@@ -134,10 +134,13 @@ def test_ols_set_taps_and_restart(monkeypatch):
         assert ulp_diff_f32(d_out[:K * F].cpu().numpy(), w3, floor).max() <= 1.0
 
 
-def test_ols_full_bench_size_against_bit_exact_form():
-    # BASELINE-size stream (1 Line x 2 ch x 4096 buffers of 4096 frames, float32, 256 taps):
-    # the overlap-save form against the bit-exact direct form on the device, every sample.
-    F, K, C, N = 4096, 4096, 2, 256
+@pytest.mark.parametrize("K", [4096, 131072])
+def test_ols_full_bench_size_against_bit_exact_form(K):
+    # BASELINE-size streams (1 Line x 2 ch x K buffers of 4096 frames, float32, 256 taps; K = 131072
+    # is bench.py's default step: 4.3 GB per buffer, offsets beyond 32 bits): the overlap-save form
+    # against the bit-exact direct form on the device, every sample, and the direct form's last
+    # frames against the oracle.
+    F, C, N = 4096, 2, 256
     taps = synth.fir_lowpass_taps(N, f32_rounded=True)
     n = K * F * C
     d_in = torch.empty(n, dtype=torch.float32, device="cuda")
@@ -170,6 +173,10 @@ def test_ols_full_bench_size_against_bit_exact_form():
     assert max_ulp_big <= 1
     assert small_abs <= float(np.spacing(np.float32(floor)))
     assert n_diff / n < 1e-5
+    lo = n // C - 4000  # 64-bit addressing: the end of the stream against the oracle
+    x = d_in[lo * C:].cpu().numpy().reshape(-1, C).astype(np.float64)
+    want = O.Fir(taps, C).process(x).reshape(-1, C)[N:].astype(np.float32)
+    assert np.array_equal(y_ref[(lo + N) * C:].cpu().numpy().reshape(-1, C), want)
 
 
 def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
