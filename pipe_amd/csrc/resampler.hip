@@ -75,9 +75,33 @@ struct TiledArgs {
     int plane;     // plane stride (elements)
     int cx_log;    // log2 of staging columns (pow2 >= C)
     int tiles_per_line;
+    int tile_out;  // output frames per tile (kOutTile, or a multiple of q when the taps sit in registers)
+    int q;         // lanes that compute: the outputs of lane l are l, l + q, l + 2q, ... of the tile
 };
 
 // CH channels of one output frame: acc[c] = fma(h[j], x_c[n-j], acc[c]), j ascending
+// The same with the lane's T = TT taps in registers: when every output of a lane has the same
+// phase (its outputs are a multiple of `up` apart) the taps are read from the table once per
+// launch instead of once per output -- a third of the bytes this kernel moves through LDS.
+template <int CH, int TT, typename TOut>
+__device__ __forceinline__ void resample_taps_reg(const double (&h)[TT > 0 ? TT : 1], const double *__restrict__ xp,
+                                                  int plane, TOut *__restrict__ o)
+{
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        acc[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            acc[c] = __builtin_fma(h[j], xp[c * plane - j], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        o[c] = (TOut)acc[c];
+}
+
 template <int CH, typename TOut>
 __device__ __forceinline__ void resample_taps(const double *__restrict__ hp, const double *__restrict__ xp,
                                               int T, int up, int plane, TOut *__restrict__ o)
@@ -100,7 +124,7 @@ __device__ __forceinline__ void resample_taps(const double *__restrict__ hp, con
         o[c] = (TOut)acc[c];
 }
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, int TT>
 __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArgs t)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -126,13 +150,26 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
         }
     }
 
+    // TT > 0: this lane's outputs all have phase p = (r0 + lane*down) mod up, where r0 is the
+    // phase of the call's first output (tiles are a multiple of `up` outputs long): its taps
+    // h[j] = proto[p + j*up] are fetched once
+    double hreg[TT > 0 ? TT : 1];
+    if constexpr (TT > 0) {
+        __syncthreads();  // the table is complete
+        const unsigned r_call = (unsigned)((a.out_total * a.down) % a.up);
+        const unsigned p = (r_call + (unsigned)threadIdx.x * (unsigned)a.down) % (unsigned)a.up;
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+            hreg[j] = tab[p + j * a.up];
+    }
+
     const int ntiles = t.tiles_per_line * a.lines;
     for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
     const int line = tile_id / t.tiles_per_line;
     const int tile = tile_id - line * t.tiles_per_line;
-    const int64_t m0 = a.out_total + (int64_t)tile * kOutTile;  // first output (global index)
-    const int64_t i0 = (int64_t)tile * kOutTile;                // ... relative to this call
-    const int nout = (int)min((int64_t)kOutTile, a.out_frames - i0);
+    const int64_t m0 = a.out_total + (int64_t)tile * t.tile_out;  // first output (global index)
+    const int64_t i0 = (int64_t)tile * t.tile_out;                // ... relative to this call
+    const int nout = (int)min((int64_t)t.tile_out, a.out_frames - i0);
 
     // input frame (relative to this call's input) read by the tile's first output, minus history
     const int64_t t0 = m0 * a.down;
@@ -175,7 +212,7 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
     __syncthreads();
 
     TOut *__restrict__ out = reinterpret_cast<TOut *>(a.out) + ((int64_t)line * a.out_cap + i0) * a.C;
-    for (int ml = threadIdx.x; ml < nout; ml += kThreads) {
+    for (int ml = threadIdx.x; ml < nout && (int)threadIdx.x < t.q; ml += t.q) {
         const unsigned tt = r0 + (unsigned)ml * (unsigned)a.down;  // < up + 1024*down: fits 32 bits
         const unsigned nrel = tt / (unsigned)a.up;                 // input frame relative to nfirst
         const unsigned p = tt - nrel * (unsigned)a.up;
@@ -187,7 +224,18 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
             const int left = a.C - c0;
             const double *__restrict__ xp = x + c0 * t.plane;
             TOut *__restrict__ o = out + (int64_t)ml * a.C + c0;
-            if (left >= 8) {
+            if constexpr (TT > 0) {
+                if (left >= 4) {
+                    resample_taps_reg<4, TT>(hreg, xp, t.plane, o);
+                    c0 += 4;
+                } else if (left >= 2) {
+                    resample_taps_reg<2, TT>(hreg, xp, t.plane, o);
+                    c0 += 2;
+                } else {
+                    resample_taps_reg<1, TT>(hreg, xp, t.plane, o);
+                    c0 += 1;
+                }
+            } else if (left >= 8) {
                 resample_taps<8>(h, xp, a.T, a.up, t.plane, o);
                 c0 += 8;
             } else if (left >= 4) {
@@ -293,8 +341,14 @@ public:
         a.down = down_;
         a.lines = cfg.lines;
         const int64_t total = n_out * cfg.channels * cfg.lines;
-        // staged window of a tile: frames read by kOutTile outputs, plus history, plus slack
-        const int win = (int)(((int64_t)kOutTile * down_ + up_ - 1) / up_) + T_ + 1;
+        // taps in registers: T one of the specialised sizes and `up` small enough that a
+        // workgroup's lanes cover whole periods of the phase pattern
+        const bool reg_taps = (T_ == 8 || T_ == 12 || T_ == 16 || T_ == 24 || T_ == 32) && up_ <= kThreads &&
+                              !std::getenv("PIPE_HIP_RESAMPLE_LDS_TAPS");
+        const int q = reg_taps ? up_ * (kThreads / up_) : kThreads;
+        const int tile_out = reg_taps ? q * (kOutTile / q) : kOutTile;
+        // staged window of a tile: frames read by tile_out outputs, plus history, plus slack
+        const int win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
         int plane = win + 1;
         plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
         const size_t lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
@@ -307,25 +361,35 @@ public:
             t.cx_log = 0;
             while ((1 << t.cx_log) < cfg.channels)
                 ++t.cx_log;
-            t.tiles_per_line = (int)((n_out + kOutTile - 1) / kOutTile);
+            t.tile_out = tile_out;
+            t.q = q;
+            t.tiles_per_line = (int)((n_out + tile_out - 1) / tile_out);
             const int64_t ntiles = (int64_t)t.tiles_per_line * cfg.lines;
             const int64_t slots = 3 * 256;  // ~3 workgroups per CU keep the table amortised
             const int64_t per = (ntiles + slots - 1) / slots;
             const dim3 grid((unsigned)((ntiles + per - 1) / per));
             PH_TRY(timer.begin(s));
-            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
-                hipLaunchKernelGGL((resample_tiled_kernel<float, float>), grid, dim3(kThreads), lds, s, t);
-                last_kernel = "resample_tiled_kernel<f32,f32>";
-            } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
-                hipLaunchKernelGGL((resample_tiled_kernel<double, double>), grid, dim3(kThreads), lds, s, t);
-                last_kernel = "resample_tiled_kernel<f64,f64>";
-            } else if (in_dtype == PIPE_HIP_F32) {
-                hipLaunchKernelGGL((resample_tiled_kernel<float, double>), grid, dim3(kThreads), lds, s, t);
-                last_kernel = "resample_tiled_kernel<f32,f64>";
-            } else {
-                hipLaunchKernelGGL((resample_tiled_kernel<double, float>), grid, dim3(kThreads), lds, s, t);
-                last_kernel = "resample_tiled_kernel<f64,f32>";
-            }
+#define PH_RS(TI, TO, NAME)                                                                              \
+    do {                                                                                                 \
+        switch (reg_taps ? T_ : 0) {                                                                     \
+        case 8: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 8>), grid, dim3(kThreads), lds, s, t); break;   \
+        case 12: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 12>), grid, dim3(kThreads), lds, s, t); break; \
+        case 16: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(kThreads), lds, s, t); break; \
+        case 24: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(kThreads), lds, s, t); break; \
+        case 32: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(kThreads), lds, s, t); break; \
+        default: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(kThreads), lds, s, t); break;  \
+        }                                                                                                \
+        last_kernel = NAME;                                                                              \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_RS(float, float, "resample_tiled_kernel<f32,f32>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_RS(double, double, "resample_tiled_kernel<f64,f64>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_RS(float, double, "resample_tiled_kernel<f32,f64>");
+            else
+                PH_RS(double, float, "resample_tiled_kernel<f64,f32>");
+#undef PH_RS
             PH_HIP(hipGetLastError());
             PH_TRY(timer.end(s));
         } else if (total > 0) {
