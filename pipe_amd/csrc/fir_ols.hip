@@ -178,6 +178,30 @@ __device__ __forceinline__ void twiddle(cd (&v)[16], const double2 *__restrict__
     }
 }
 
+// The W64^(a*d) twiddles, applied where a already sits in the register index (r = 4i + a) and
+// j = d & 3 in the 16-lane row: t[r] = W64^(a*(4i + j)) for this lane's row.  The four registers
+// with a = 0 are multiplied by one: twelve products instead of fifteen.
+template <bool CONJ>
+__device__ __forceinline__ void twiddle_rows(cd (&v)[16], const double2 *__restrict__ t)
+{
+    constexpr int G = 4;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        double2 w[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            w[i] = t[4 * i + g + 1];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int r = 4 * i + g + 1;
+            const cd ww{w[i].x, w[i].y};
+            v[r] = CONJ ? cmulc(v[r], ww) : cmul(v[r], ww);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // X2 without LDS.  Before: lane = k2 + 16*a (a = the 16-lane row), register d = 4i + j.  The last
 // radix-4 step runs over a, so a has to come into registers: for every i the 4x4 block
 // (row a) x (register j) is transposed with the cross-row swap instructions of gfx950 --
@@ -337,7 +361,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const int k2l = lane & 15, al = lane >> 4;  // L1: lane = k2 + 16*a
     const int64_t last = a.frames - 1;
     // twiddle rows: step B reads tw1s[(k2-1)*64 + n1] (consecutive lanes, consecutive slots),
-    // step C2 reads tw2s[a*16 + d] (one slot per 16-lane row: a broadcast)
+    // step C2 reads tw2s[j*16 + r] (j = this lane's 16-lane row after the transpose: a broadcast)
     const double2 *__restrict__ twB = tw1s + n1 - 64;  // indexed with k2*64
     const double2 *__restrict__ twC = tw2s + al * 16;
     // spectrum entry of register r = 4i + c is frequency k = 256c + 64i + lane; for c >= 2 it is
@@ -505,9 +529,9 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         // X1: (lane n1, reg k2) -> (lane k2 + 16a, reg b) holding element (a + 4b, k2)
         exchange(v, x1_lane, x1_grp);
         dft16<-1>(v);    // C1: over b -> d
-        twiddle<false>(v, twC, 1);   // C2: W64^(a*d)
         // X2: (lane k2 + 16a, reg d = 4i + j) -> (lane k2 + 16j, reg 4i + a), in registers
         rows_to_regs<true>(v);
+        twiddle_rows<false>(v, twC);  // C2: W64^(a*d), d = 4i + j; a = 0 needs none
 #pragma unroll
         for (int q = 0; q < 4; ++q)  // C3: over a -> c
             dft4<-1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -529,8 +553,8 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             dft4<+1>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        twiddle_rows<true>(v, twC);
         rows_to_regs<false>(v);
-        twiddle<true>(v, twC, 1);
         dft16<+1>(v);    // over d -> b
         exchange(v, x1_grp, x1_lane);
         twiddle<true>(v, twB, 64);
@@ -618,11 +642,14 @@ int Plan::init(int device, const double *taps, int ntaps)
             t1[2 * (k2 * 64 + n1)] = (double)cosl(ang);
             t1[2 * (k2 * 64 + n1) + 1] = (double)sinl(ang);
         }
-    for (int a = 0; a < 4; ++a)
-        for (int d = 0; d < 16; ++d) {
-            const long double ang = -2.0L * (long double)kPi * (a * d) / 64;
-            t2[2 * (a * 16 + d)] = (double)cosl(ang);
-            t2[2 * (a * 16 + d) + 1] = (double)sinl(ang);
+    // W64^(a*d) laid out for the point where the kernel applies it: row j = d & 3 of the wave,
+    // register r = 4i + a (d = 4i + j)
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const int i = r >> 2, a = r & 3;
+            const long double ang = -2.0L * (long double)kPi * (a * (4 * i + j)) / 64;
+            t2[2 * (j * 16 + r)] = (double)cosl(ang);
+            t2[2 * (j * 16 + r) + 1] = (double)sinl(ang);
         }
     PH_TRY(impl_->tw1.alloc(sizeof(double) * t1.size()));
     PH_TRY(impl_->tw2.alloc(sizeof(double) * t2.size()));
