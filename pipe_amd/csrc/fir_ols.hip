@@ -157,7 +157,7 @@ __device__ __forceinline__ void twiddle(cd (&v)[16], const double2 *__restrict__
 {
     constexpr int G = 5;
     double2 w[2][G];
-    __builtin_amdgcn_sched_barrier(0);
+    /* no leading barrier: the first reads may start under the preceding DFT */
 #pragma unroll
     for (int j = 0; j < G; ++j)
         w[0][j] = t[(1 + j) * stride];
