@@ -55,8 +55,19 @@ typedef enum pipe_hip_param {
     PIPE_HIP_PARAM_COEFFS = 2, /* nsections*5 values {b0,b1,b2,a1,a2} */
     PIPE_HIP_PARAM_EXACT = 3   /* 1 value: != 0 pins the stage to its ordered-fma form (bit-exact vs
                                   the oracle) even for float32 results, which otherwise may use the
-                                  FIR's overlap-save FFT form / the biquad's time-segmented form
-                                  (both <= 1 ulp f32).  float64 buffers always take the exact form.
+                                  FIR's overlap-save FFT form / the biquad's time-segmented form /
+                                  the fused FIR+biquad+gain chain kernel.  Those "relaxed" forms are
+                                  chosen by CALL SIZE (large device-resident batches only, thresholds
+                                  in DESIGN.md), so the same stream can give different last bits for
+                                  different batch sizes or devices.  Their bound, as tested: the
+                                  float64 value differs from the oracle's by O(1e-16) of the filter's
+                                  full-scale output, i.e. the float32 result is within one float32
+                                  ulp measured at max(|y|, 2^-24 * ||h||_1 * max|x|) -- relative to
+                                  the window's full scale, NOT to a quiet sample next to loud ones
+                                  (stop-band outputs can be off by many of THEIR ulps).  The
+                                  biquad's relaxed forms propagate segment states through powers of
+                                  the state-transition matrix: sound for stable sections only.
+                                  float64 buffers always take the exact form.
                                   On a chain it applies to every stage.  The relaxed forms mix
                                   the samples of a 1024-frame window / a segment, so a NaN or Inf
                                   input reaches more outputs than in the ordered form: set this
@@ -129,10 +140,13 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
 /* One step of MANY Lines through one handle (cfg.lines = L): the batched form of the
  * multiLineExecutor pass (run.go:112-132), which calls ProcessFunc once per Line.  ins[l] /
  * outs[l] are the HOST buffers of Line l (its own pool buffers, not contiguous with the
- * others); in_frames[l] <= buffer_size may differ per Line (short last buffers): shorter
- * Lines are zero-padded on the device and only their own frames are written back, a NULL
- * ins[l] is a Line that has ended.  out_frames[l] (optional) receives in_frames[l].
- * Fixed-rate processors only.  Synchronous. */
+ * others); in_frames[l] <= buffer_size may differ per Line -- a short LAST buffer, or a short
+ * read in the middle of a stream (pipe.go:404-406): every Line's state advances by exactly its
+ * own in_frames[l] (the pass is cut into runs of consecutive Lines with equal counts, one launch
+ * per run; the usual pass, all live Lines equal, is one launch).  A NULL ins[l] is a Line that
+ * has ended: its state is undefined until the next pipe_hip_start.  in_frames[l] == 0 with a
+ * buffer is an empty read: that Line is not advanced.  out_frames[l] (optional) receives
+ * in_frames[l].  Fixed-rate processors only.  Synchronous. */
 int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
                            void *const *outs, int32_t *out_frames);
 /* The same step when every ins[l] / outs[l] was allocated with pipe_hip_host_alloc (pinned,
@@ -153,8 +167,13 @@ int pipe_hip_submit(pipe_hip_processor *p, const void *in, int32_t in_frames);
 int pipe_hip_collect(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames);
 
 /* A mutable.Mutation body (mutable/mutable.go:40-48) for this component: takes
- * effect for the next buffer and never for one already submitted (pipe.go:433). */
+ * effect for the next buffer and never for one already submitted (pipe.go:433).
+ * On a chain the parameter goes to the first stage that accepts it (EXACT: to all). */
 int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *values, int32_t count);
+/* The same for stage `stage` (0-based) of a chain: needed when two stages take the same
+ * parameter (two FIRs with equal tap counts). */
+int pipe_hip_chain_set_param(pipe_hip_processor *chain, int32_t stage, int32_t param, const double *values,
+                             int32_t count);
 
 /* ---- device-resident batch (multiLineExecutor step, run.go:112-132, widened on
  * the time axis): every Line advances by frames_per_line frames in one launch.

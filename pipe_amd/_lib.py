@@ -91,6 +91,7 @@ def lib():
         "pipe_hip_submit": (C.c_int, [vp, vp, i32]),
         "pipe_hip_collect": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "pipe_hip_set_param": (C.c_int, [vp, i32, dp, i32]),
+        "pipe_hip_chain_set_param": (C.c_int, [vp, i32, i32, dp, i32]),
         "pipe_hip_process_batch": (C.c_int, [vp, vp, vp, i64, vp]),
         "pipe_hip_resample_batch": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(i64), vp]),
         "pipe_hip_mix_batch": (C.c_int, [vp, hp, i32, vp, i64, vp]),

@@ -3,6 +3,7 @@
 // pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
 // bracket used for live kernel timing.
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -157,9 +158,10 @@ int pipe_hip_processor::ensure_staging()
     if (d_in.p)
         return PIPE_HIP_OK;
     const size_t es = dtype_size(cfg.dtype);
-    const size_t in_b = es * (size_t)cfg.lines * (size_t)cfg.buffer_size * (size_t)cfg.channels;
+    // (+16 bytes per Line: the runs of a ragged pipe_hip_process_lines pass start 16-byte aligned)
+    const size_t in_b = es * (size_t)cfg.lines * (size_t)cfg.buffer_size * (size_t)cfg.channels + 16u * (size_t)cfg.lines;
     const size_t out_f = (size_t)max_out_frames(cfg.buffer_size);
-    const size_t out_b = es * (size_t)cfg.lines * out_f * (size_t)out_channels();
+    const size_t out_b = es * (size_t)cfg.lines * out_f * (size_t)out_channels() + 16u * (size_t)cfg.lines;
     PH_TRY(d_in.alloc(in_b));
     PH_TRY(d_out.alloc(out_b));
     PH_TRY(h_in.alloc(in_b));
@@ -424,6 +426,76 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
     return collect_impl(p, out, out_cap_frames, out_frames);
 }
 
+// ---- one pass of many Lines (run.go:112-132 batched) ---------------------------------
+// A pass is cut into RUNS of consecutive Lines that bring the same frame count; each run is one
+// launch over exactly its Lines (set_window), so every Line's state advances by its own frames --
+// also when a Source returns a short read in the middle of its stream and keeps going
+// (pipe.go:404-406).  The normal pass (every live Line brings the same count) is one run.
+namespace {
+
+struct LineRun {
+    int first, count;
+    int32_t frames;
+    size_t in_off, out_off;  // byte offsets of the run's packed rows in the staging buffers
+};
+
+int plan_line_runs(const pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
+                   void *const *outs, std::vector<LineRun> *runs)
+{
+    const int L = p->cfg.lines;
+    const size_t es = dtype_size(p->cfg.dtype);
+    runs->clear();
+    int32_t common = -1;
+    bool uniform = true;
+    for (int l = 0; l < L; ++l) {
+        if (in_frames[l] < 0 || in_frames[l] > p->cfg.buffer_size || (ins[l] && in_frames[l] > 0 && !outs[l]))
+            return PIPE_HIP_EINVAL;
+        if (!ins[l])
+            continue;  // a Line that has ended: it rides along zero-padded, its state is dead
+        if (common < 0)
+            common = in_frames[l];
+        else if (in_frames[l] != common)
+            uniform = false;
+    }
+    if (common < 0)
+        return PIPE_HIP_OK;  // nothing live
+    if (uniform) {
+        if (common > 0)
+            runs->push_back(LineRun{0, L, common, 0, 0});
+        return PIPE_HIP_OK;
+    }
+    size_t in_off = 0, out_off = 0;
+    for (int l = 0; l < L;) {
+        if (!ins[l] || in_frames[l] == 0) {  // ended, or an empty read: not advanced
+            ++l;
+            continue;
+        }
+        const int32_t f = in_frames[l];
+        int end = l + 1, last_live = l;
+        while (end < L && (!ins[end] || in_frames[end] == f)) {
+            if (ins[end])
+                last_live = end;
+            ++end;
+        }
+        const int n = last_live - l + 1;
+        runs->push_back(LineRun{l, n, f, in_off, out_off});
+        in_off += es * (size_t)f * (size_t)p->cfg.channels * (size_t)n;
+        out_off += es * (size_t)f * (size_t)p->out_channels() * (size_t)n;
+        // 16-byte alignment of the next run's rows (vector loads in the kernels)
+        in_off = (in_off + 15) & ~(size_t)15;
+        out_off = (out_off + 15) & ~(size_t)15;
+        l = last_live + 1;
+    }
+    return PIPE_HIP_OK;
+}
+
+struct WindowGuard {  // whatever happens, the handle goes back to "all Lines"
+    pipe_hip_processor *p;
+    ~WindowGuard() { p->set_window(0, 0); }
+};
+
+}  // namespace
+
 int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
                            void *const *outs, int32_t *out_frames)
 {
@@ -434,40 +506,50 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
     PH_TRY(p->select_device());
     PH_TRY(p->ensure_staging());
     const int L = p->cfg.lines;
-    int32_t frames = 0;
-    for (int l = 0; l < L; ++l) {
-        if (in_frames[l] < 0 || in_frames[l] > p->cfg.buffer_size || (ins[l] && in_frames[l] > 0 && !outs[l]))
-            return PIPE_HIP_EINVAL;
-        if (ins[l] && in_frames[l] > frames)
-            frames = in_frames[l];
-    }
+    std::vector<LineRun> runs;
+    PH_TRY(plan_line_runs(p, ins, in_frames, outs, &runs));
     if (out_frames)
         for (int l = 0; l < L; ++l)
             out_frames[l] = ins[l] ? in_frames[l] : 0;
-    if (frames == 0)
+    if (runs.empty())
         return PIPE_HIP_OK;
     const size_t es = dtype_size(p->cfg.dtype);
-    const size_t row_in = es * (size_t)frames * (size_t)p->cfg.channels;
-    const size_t row_out = es * (size_t)frames * (size_t)p->out_channels();
-    // gather: Line l occupies [l][frames][channels] of the pinned staging buffer
-    for (int l = 0; l < L; ++l) {
-        char *dst = static_cast<char *>(p->h_in.p) + row_in * l;
-        const size_t have = ins[l] ? es * (size_t)in_frames[l] * (size_t)p->cfg.channels : 0;
-        if (have)
-            std::memcpy(dst, ins[l], have);
-        if (have < row_in)
-            std::memset(dst + have, 0, row_in - have);
+    WindowGuard guard{p};
+    // gather: Line l of a run occupies [l - first][frames][channels] of the run's staging rows
+    for (const LineRun &r : runs) {
+        const size_t row_in = es * (size_t)r.frames * (size_t)p->cfg.channels;
+        for (int i = 0; i < r.count; ++i) {
+            const int l = r.first + i;
+            char *dst = static_cast<char *>(p->h_in.p) + r.in_off + row_in * (size_t)i;
+            const size_t have = ins[l] ? es * (size_t)in_frames[l] * (size_t)p->cfg.channels : 0;
+            if (have)
+                std::memcpy(dst, ins[l], have);
+            if (have < row_in)
+                std::memset(dst + have, 0, row_in - have);
+        }
     }
-    int64_t produced = frames;
-    PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, row_in * L, hipMemcpyHostToDevice, p->stream));
-    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, frames, p->d_out.p, p->cfg.dtype, frames, &produced, p->stream));
-    PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, row_out * L, hipMemcpyDeviceToHost, p->stream));
+    for (const LineRun &r : runs) {
+        const size_t row_in = es * (size_t)r.frames * (size_t)p->cfg.channels;
+        const size_t row_out = es * (size_t)r.frames * (size_t)p->out_channels();
+        int64_t produced = r.frames;
+        p->set_window(r.first, r.count == L ? 0 : r.count);
+        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->d_in.p) + r.in_off, static_cast<char *>(p->h_in.p) + r.in_off,
+                              row_in * (size_t)r.count, hipMemcpyHostToDevice, p->stream));
+        PH_TRY(p->run_var(static_cast<char *>(p->d_in.p) + r.in_off, p->cfg.dtype, r.frames,
+                          static_cast<char *>(p->d_out.p) + r.out_off, p->cfg.dtype, r.frames, &produced, p->stream));
+        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->h_out.p) + r.out_off, static_cast<char *>(p->d_out.p) + r.out_off,
+                              row_out * (size_t)r.count, hipMemcpyDeviceToHost, p->stream));
+    }
     PH_HIP(hipStreamSynchronize(p->stream));
-    for (int l = 0; l < L; ++l) {
-        if (!ins[l] || in_frames[l] == 0)
-            continue;
-        std::memcpy(outs[l], static_cast<const char *>(p->h_out.p) + row_out * l,
-                    es * (size_t)in_frames[l] * (size_t)p->out_channels());
+    for (const LineRun &r : runs) {
+        const size_t row_out = es * (size_t)r.frames * (size_t)p->out_channels();
+        for (int i = 0; i < r.count; ++i) {
+            const int l = r.first + i;
+            if (!ins[l] || in_frames[l] == 0)
+                continue;
+            std::memcpy(outs[l], static_cast<const char *>(p->h_out.p) + r.out_off + row_out * (size_t)i,
+                        es * (size_t)in_frames[l] * (size_t)p->out_channels());
+        }
     }
     return PIPE_HIP_OK;
 }
@@ -486,17 +568,12 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
     const size_t fb_in = es * (size_t)p->cfg.channels, fb_out = es * (size_t)p->out_channels();
     if (fb_in % 8 != 0 || fb_out % 8 != 0)  // the row kernels move 8-byte words
         return pipe_hip_process_lines(p, ins, in_frames, outs, out_frames);
-    int32_t frames = 0;
-    for (int l = 0; l < L; ++l) {
-        if (in_frames[l] < 0 || in_frames[l] > p->cfg.buffer_size || (ins[l] && in_frames[l] > 0 && !outs[l]))
-            return PIPE_HIP_EINVAL;
-        if (ins[l] && in_frames[l] > frames)
-            frames = in_frames[l];
-    }
+    std::vector<LineRun> runs;
+    PH_TRY(plan_line_runs(p, ins, in_frames, outs, &runs));
     if (out_frames)
         for (int l = 0; l < L; ++l)
             out_frames[l] = ins[l] ? in_frames[l] : 0;
-    if (frames == 0)
+    if (runs.empty())
         return PIPE_HIP_OK;
     // tables the kernels read: [L] in pointers, [L] out pointers, [L] in words, [L] out words
     const size_t tab_bytes = (size_t)L * (2 * sizeof(void *) + 2 * sizeof(int));
@@ -513,10 +590,18 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
         win[l] = live ? (int)((size_t)in_frames[l] * fb_in / 8) : 0;
         wout[l] = live ? (int)((size_t)in_frames[l] * fb_out / 8) : 0;
     }
-    int64_t produced = frames;
-    PH_TRY(launch_gather_rows(tin, win, p->d_in.p, (int)((size_t)frames * fb_in / 8), L, p->stream));
-    PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, frames, p->d_out.p, p->cfg.dtype, frames, &produced, p->stream));
-    PH_TRY(launch_scatter_rows(tout, wout, p->d_out.p, (int)((size_t)frames * fb_out / 8), L, p->stream));
+    WindowGuard guard{p};
+    for (const LineRun &r : runs) {
+        int64_t produced = r.frames;
+        char *din = static_cast<char *>(p->d_in.p) + r.in_off;
+        char *dout = static_cast<char *>(p->d_out.p) + r.out_off;
+        p->set_window(r.first, r.count == L ? 0 : r.count);
+        PH_TRY(launch_gather_rows(tin + r.first, win + r.first, din, (int)((size_t)r.frames * fb_in / 8), r.count,
+                                  p->stream));
+        PH_TRY(p->run_var(din, p->cfg.dtype, r.frames, dout, p->cfg.dtype, r.frames, &produced, p->stream));
+        PH_TRY(launch_scatter_rows(tout + r.first, wout + r.first, dout, (int)((size_t)r.frames * fb_out / 8), r.count,
+                                   p->stream));
+    }
     PH_HIP(hipStreamSynchronize(p->stream));
     return PIPE_HIP_OK;
 }
@@ -526,7 +611,7 @@ int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t 
 {
     if (!p || !ins || frames < 0 || frames > p->cfg.buffer_size || n_inputs < 2 || n_inputs > 8)
         return PIPE_HIP_EINVAL;
-    if (p->single_input())
+    if (p->single_input() || (frames > 0 && !out))
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     const size_t es = dtype_size(p->cfg.dtype);
@@ -566,6 +651,15 @@ int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *value
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     return p->set_param(param, values, count);
+}
+
+int pipe_hip_chain_set_param(pipe_hip_processor *p, int32_t stage, int32_t param, const double *values,
+                             int32_t count)
+{
+    if (!p || !values || count < 1)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->select_device());
+    return p->set_stage_param(stage, param, values, count);
 }
 
 int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,

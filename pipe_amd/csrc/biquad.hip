@@ -474,14 +474,16 @@ public:
         if (frames <= 0)
             return PIPE_HIP_OK;
         BiquadArgs a{};
-        a.state = static_cast<double *>(state_.p);
+        // (a window of Lines: the state slice of exactly those Lines)
+        const int nl = active_lines();
+        a.state = static_cast<double *>(state_.p) + (size_t)win_first * (size_t)cfg.channels * (size_t)S_ * 2u;
         a.frames = frames;
         a.C = cfg.channels;
         a.S = S_;
-        a.nseries = cfg.lines * cfg.channels;
+        a.nseries = nl * cfg.channels;
         a.gain = gain_;
-        a.in_bytes = (int64_t)dtype_size(in_dtype) * frames * cfg.channels * cfg.lines;
-        a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * cfg.lines;
+        a.in_bytes = (int64_t)dtype_size(in_dtype) * frames * cfg.channels * nl;
+        a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * nl;
         if (a.in_bytes >= ((int64_t)1 << 32) - 4096 || a.out_bytes >= ((int64_t)1 << 32) - 4096)
             return PIPE_HIP_EINVAL;  // 32-bit buffer offsets: split the call (never reached by buffer_size*max_batch in practice)
         const unsigned sblocks = (unsigned)((a.nseries + kThreads - 1) / kThreads);
@@ -572,7 +574,7 @@ public:
                 fb = (frames + kLdsChunk - 1) / kLdsChunk * kLdsChunk;
             la.fb = (int)fb;
             const size_t lds = sizeof(double) * (size_t)fb * (size_t)cg;
-            const dim3 grid((unsigned)(cfg.lines * la.cgroups));
+            const dim3 grid((unsigned)(nl * la.cgroups));
 #define PH_BQ2(TI, TO, G)                                                                              \
     do {                                                                                               \
         if (S_ == 1)                                                                                   \
@@ -649,7 +651,7 @@ public:
         static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");
         if (env)
             return std::atoi(env) != 0;
-        return cfg.lines * ((cfg.channels + 63) / 64) <= 256 && cfg.lines * cfg.channels <= 2048;
+        return active_lines() * ((cfg.channels + 63) / 64) <= 256 && active_lines() * cfg.channels <= 2048;
     }
 
     void launch_scan(unsigned sblocks, hipStream_t s, const BiquadArgs &a, const BiquadTransition &mlast)

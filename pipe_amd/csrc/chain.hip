@@ -66,6 +66,12 @@ public:
         last_kernel = stages.empty() ? "" : stages[0]->last_kernel;
         return PIPE_HIP_OK;
     }
+    void set_window(int first, int count) override
+    {
+        pipe_hip_processor::set_window(first, count);
+        for (auto &st : stages)
+            st->set_window(first, count);
+    }
     // a mutation addressed to the chain goes to the first stage that owns the parameter
     int set_param(int32_t param, const double *values, int32_t count) override
     {
@@ -81,6 +87,12 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
+    int set_stage_param(int32_t stage, int32_t param, const double *values, int32_t count) override
+    {
+        if (stage < 0 || (size_t)stage >= stages.size())
+            return PIPE_HIP_EINVAL;
+        return stages[(size_t)stage]->set_param(param, values, count);
+    }
 
 private:
     DevBuf tmp_[2];
@@ -90,7 +102,7 @@ private:
 
 int make_chain(pipe_hip_processor *const *stages, int32_t n, pipe_hip_processor **out)
 {
-    if (!stages || n < 1 || n > 16)
+    if (!stages || n < 1 || n > 16 || !stages[0])
         return PIPE_HIP_EINVAL;
     const pipe_hip_config c0 = stages[0]->cfg;
     for (int i = 0; i < n; ++i) {

@@ -138,6 +138,20 @@ struct pipe_hip_processor {
     // the stage may then use a form that is exact to O(1e-16) instead of bit-exact
     bool relaxed_f64_out = false;
 
+    // The Lines one run() advances: [win_first, win_first + win_count) of cfg.lines; the
+    // buffers passed to run() then hold only those Lines, packed.  win_count == 0: all Lines
+    // (the default).  pipe_hip_process_lines narrows it when the Lines of one pass bring
+    // different frame counts (a short read in the middle of a stream, pipe.go:404-406): every
+    // Line's state must advance by its OWN frames.
+    int win_first = 0, win_count = 0;
+    int active_lines() const { return win_count > 0 ? win_count : cfg.lines; }
+    bool windowed() const { return win_count > 0 && win_count < cfg.lines; }
+    virtual void set_window(int first, int count)
+    {
+        win_first = count > 0 ? first : 0;
+        win_count = count;
+    }
+
     virtual ~pipe_hip_processor();
 
     // properties of the OUTPUT signal
@@ -174,6 +188,15 @@ struct pipe_hip_processor {
     virtual bool fixed_rate() const { return true; }
     virtual int set_param(int32_t param, const double *values, int32_t count)
     {
+        (void)param;
+        (void)values;
+        (void)count;
+        return PIPE_HIP_EINVAL;
+    }
+    // chains only: a parameter of stage `stage`
+    virtual int set_stage_param(int32_t stage, int32_t param, const double *values, int32_t count)
+    {
+        (void)stage;
         (void)param;
         (void)values;
         (void)count;

@@ -154,7 +154,7 @@ public:
     int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
             hipStream_t s) override
     {
-        const int64_t n = frames * cfg.channels * cfg.lines;
+        const int64_t n = frames * cfg.channels * active_lines();
         if (n <= 0)
             return PIPE_HIP_OK;
         int vec_ok = aligned_to(d_in, dtype_size(in_dtype) * kPer) &&

@@ -435,15 +435,19 @@ public:
     {
         if (frames <= 0)
             return PIPE_HIP_OK;
-        const double *hist = static_cast<const double *>(hist_[cur_hist_].p);
+        // a window of Lines (pipe_hip_process_lines with ragged lengths): the per-Line history
+        // slices of exactly those Lines
+        const int nl = active_lines();
+        const size_t hoff = (size_t)win_first * (size_t)H_ * (size_t)cfg.channels;
+        const double *hist = static_cast<const double *>(hist_[cur_hist_].p) + hoff;
         // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
         if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
-            ols_->items(frames, cfg.channels, cfg.lines) >= ols_min_items()) {
-            PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, hist_next(), frames, cfg.channels,
-                             cfg.lines, s, &last_kernel, &timer));
-            return flip_history();
+            ols_->items(frames, cfg.channels, nl) >= ols_min_items()) {
+            PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, frames, cfg.channels,
+                             nl, s, &last_kernel, &timer));
+            return flip_history(s);
         }
         Geometry g;
         if (!choose(frames, &g))
@@ -454,7 +458,7 @@ public:
         a.line_stride = frames * cfg.channels;
         a.C = cfg.channels;
         a.CG = g.CG;
-        a.lines = cfg.lines;
+        a.lines = nl;
         a.tiles_per_line = (int)g.tiles_per_line;
         a.ntiles = (int)g.ntiles;
         a.N = N_;
@@ -471,9 +475,9 @@ public:
         a.out_off = (int)g.out_off;
         a.out_slab = g.out_slab;
         a.taps_off = (int)g.taps_off;
-        a.hist_new = hist_next();
+        a.hist_new = hist_next() + hoff;
         PH_TRY(launch(g, in_dtype, out_dtype, d_in, d_out, hist, taps, a, s));
-        return flip_history();
+        return flip_history(s);
     }
 
 private:
@@ -488,10 +492,20 @@ private:
     // new history = last N-1 frames of (old history ++ this call's input)
     // the launch just queued wrote the other half of the history double buffer
     double *hist_next() const { return static_cast<double *>(hist_[cur_hist_ ^ 1].p); }
-    int flip_history()
+    int flip_history(hipStream_t s)
     {
-        if (H_ > 0)
-            cur_hist_ ^= 1;
+        if (H_ <= 0)
+            return PIPE_HIP_OK;
+        if (windowed()) {
+            // only the window's Lines were advanced: bring their new history back into the
+            // current half instead of flipping the halves of every Line
+            const size_t per = sizeof(double) * (size_t)H_ * (size_t)cfg.channels;
+            PH_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)win_first,
+                                  static_cast<const char *>(hist_[cur_hist_ ^ 1].p) + per * (size_t)win_first,
+                                  per * (size_t)win_count, hipMemcpyDeviceToDevice, s));
+            return PIPE_HIP_OK;
+        }
+        cur_hist_ ^= 1;
         return PIPE_HIP_OK;
     }
 
@@ -521,7 +535,7 @@ private:
         g->taps_off = g->out_off + sizeof(double) * (size_t)g->out_slab * kWaves;
         g->lds = g->taps_off + sizeof(double) * (size_t)N_;
         g->tiles_per_line = (frames + g->TF - 1) / g->TF;
-        g->ntiles = g->tiles_per_line * cfg.lines * g->ngroups;
+        g->ntiles = g->tiles_per_line * active_lines() * g->ngroups;
         return g->lds <= kMaxLds && g->ntiles < (int64_t)1 << 30;
     }
 

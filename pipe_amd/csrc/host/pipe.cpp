@@ -675,6 +675,9 @@ struct stageMajorExecutor final : executor {
                     return e;
             }
             std::vector<Processor *> ended;
+            error abortErr;  // first failure of this stage: the remaining groups are not processed,
+                             // but every pending still gets its batchEnd (input freed, sender
+                             // closed) like the deferred Free of pipe.go:431
             for (auto &g : groups) {
                 const size_t slots = (size_t)g.first->Slots();
                 std::vector<const signal::Floating *> ins(slots, nullptr);
@@ -690,6 +693,8 @@ struct stageMajorExecutor final : executor {
                         outs[s] = &pe.pd.output;
                     }
                 }
+                if (!procErr && abortErr)
+                    procErr = abortErr;
                 if (!procErr)
                     procErr = g.first->ProcessLines(ins, outs, &processed);
                 error first;
@@ -701,9 +706,11 @@ struct stageMajorExecutor final : executor {
                     else if (e && !first)
                         first = e;
                 }
-                if (first)
-                    return first;
+                if (first && !abortErr)
+                    abortErr = first;
             }
+            if (abortErr)
+                return abortErr;
             for (Processor *pr : ended) {  // a Send refused (context done): EOF for that Line
                 for (size_t i = 0; i < lines.size(); ++i)
                     if (p < lines[i].r->processors.size() && lines[i].r->processors[p].get() == pr) {

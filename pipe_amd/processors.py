@@ -125,6 +125,56 @@ class Processor:
     def _fixed_rate(self) -> bool:
         return True
 
+    def process_lines(self, xs: Sequence[Optional[np.ndarray]], pinned: bool = False):
+        """One multiLineExecutor pass (run.go:112-132) through a handle with lines = len(xs):
+        xs[l] is Line l's buffer (frames x channels, its own length) or None for a Line that
+        has ended.  Returns the per-Line outputs (None where the Line has ended)."""
+        if len(xs) != self.lines:
+            raise ValueError("need one entry per Line")
+        out_ch, _, _ = self.output_properties()
+        keep, ins, outs, frames = [], [], [], []
+        for x in xs:
+            if x is None:
+                ins.append(None); outs.append(None); frames.append(0); keep.append(None)
+                continue
+            a = np.ascontiguousarray(x, dtype=self.dtype).reshape(-1, self.channels)
+            o = np.empty((a.shape[0], out_ch), dtype=self.dtype)
+            if pinned:
+                a, o = self._pinned_copy(a), self._pinned_like(o)
+            keep.append((a, o))
+            ins.append(a.ctypes.data); outs.append(o.ctypes.data); frames.append(a.shape[0])
+        n = self.lines
+        pin = (C.c_void_p * n)(*ins)
+        pout = (C.c_void_p * n)(*outs)
+        fr = (C.c_int32 * n)(*frames)
+        wr = (C.c_int32 * n)()
+        fn = L.lib().pipe_hip_process_lines_pinned if pinned else L.lib().pipe_hip_process_lines
+        L.check(fn(self._h, pin, fr, pout, wr), "process_lines")
+        res = []
+        for l, k in enumerate(keep):
+            if k is None:
+                res.append(None)
+                continue
+            assert wr[l] == frames[l]
+            res.append(np.array(k[1][: wr[l]], copy=True))
+        if pinned:
+            for k in keep:
+                if k is not None:
+                    for arr in k:
+                        L.lib().pipe_hip_host_free(C.c_void_p(arr.ctypes.data))
+        return res
+
+    def _pinned_like(self, a: np.ndarray) -> np.ndarray:
+        ptr = C.c_void_p()
+        L.check(L.lib().pipe_hip_host_alloc(max(a.nbytes, 16), C.byref(ptr)), "host_alloc")
+        buf = (C.c_char * max(a.nbytes, 16)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+
+    def _pinned_copy(self, a: np.ndarray) -> np.ndarray:
+        b = self._pinned_like(a)
+        b[...] = a
+        return b
+
     def submit(self, x: np.ndarray):
         x, frames = self._shape_in(x)
         L.check(L.lib().pipe_hip_submit(self._h, x.ctypes.data, frames), "submit")
@@ -142,9 +192,20 @@ class Processor:
         """d_in/d_out: torch device tensors of lines*frames*channels elements."""
         if frames_per_line is None:
             frames_per_line = d_in.numel() // (self.lines * self.channels)
+        need = self.lines * int(frames_per_line) * self.channels
+        self._check_device_tensor(d_in, need)
+        self._check_device_tensor(d_out, need)
         L.check(L.lib().pipe_hip_process_batch(self._h, _devptr(d_in), _devptr(d_out),
                                                int(frames_per_line), C.c_void_p(stream or None)),
                 "process_batch")
+
+    def _check_device_tensor(self, t, need: int):
+        import torch
+        want = torch.float64 if self.dtype == np.dtype(np.float64) else torch.float32
+        if t.dtype != want:
+            raise TypeError(f"tensor dtype {t.dtype} does not match the handle's {self.dtype}")
+        if t.numel() < need:
+            raise ValueError(f"tensor holds {t.numel()} elements, the call needs {need}")
 
     # -- measurement -------------------------------------------------------------------------
     def set_profiling(self, on: bool):
@@ -246,6 +307,10 @@ class Mix(Processor):
 
     def process(self, xs: Sequence[np.ndarray], out_cap_frames=None) -> np.ndarray:  # type: ignore[override]
         arrs = [np.ascontiguousarray(x, dtype=self.dtype) for x in xs]
+        if len(arrs) != self.inputs or any(a.size != arrs[0].size for a in arrs):
+            raise ValueError("mix: need `inputs` arrays of equal size")
+        if arrs[0].size % (self.lines * self.channels):
+            raise ValueError("input size does not match lines x frames x channels")
         frames = arrs[0].size // (self.lines * self.channels)
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         out = np.empty_like(arrs[0])
@@ -254,6 +319,9 @@ class Mix(Processor):
         return out
 
     def mix_batch(self, d_ins, d_out, frames_per_line: int, stream: int = 0):
+        need = self.lines * int(frames_per_line) * self.channels
+        for t in list(d_ins) + [d_out]:
+            self._check_device_tensor(t, need)
         ptrs = (C.c_void_p * len(d_ins))(*[_devptr(t) for t in d_ins])
         L.check(L.lib().pipe_hip_mix_batch(self._h, ptrs, len(d_ins), _devptr(d_out),
                                            int(frames_per_line), C.c_void_p(stream or None)),
@@ -273,6 +341,11 @@ class Chain(Processor):
         for s in stages:
             s._owned = True
         self.stages = list(stages)
+
+    def set_stage_param(self, stage: int, param: int, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        L.check(L.lib().pipe_hip_chain_set_param(self._h, int(stage), param, _dptr(v), v.size),
+                "chain_set_param")
 
 
 def device_count() -> int:

@@ -12,12 +12,12 @@ KEEP = ("fir_", "ols", "gain_kernel", "biquad_kernel", "resample_kernel", "mix_k
 print(f"# rocprofv3 summary for {os.path.basename(out.rstrip('/'))}")
 for p in sorted(glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True)):
     db = sqlite3.connect(p)
-    print("## kernel stats (rocprofv3 --kernel-trace --stats), ns")
+    print("## kernel stats (rocprofv3 --kernel-trace --stats); top_kernels reports MICROSECONDS")
     for name, calls, total, avg, pct in db.execute(
             "select name, total_calls, total_duration, average, percentage from top_kernels"):
-        print(f"  {name[:110]:110s} calls={calls} total_ns={total} avg_ns={avg:.0f} pct={pct:.2f}")
+        print(f"  {name[:110]:110s} calls={calls} total_us={total:.1f} avg_us={avg:.2f} pct={pct:.2f}")
     r = db.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
-                   "grid_x, grid_y, grid_z, workgroup_x from kernels where name like '%fir_direct%' limit 1").fetchone()
+                   "grid_x, grid_y, grid_z, workgroup_x from kernels where name like ? limit 1", (os.environ.get('PROF_DISPATCH_LIKE', '%fir_ols%'),)).fetchone()
     if r:
         print(f"  dispatch: {r[0][:80]} vgpr={r[1]} agpr={r[2]} sgpr={r[3]} lds={r[4]} scratch={r[5]} "
               f"grid=({r[6]},{r[7]},{r[8]}) wg={r[9]}")

@@ -177,6 +177,19 @@ def test_ols_full_bench_size_against_bit_exact_form(K):
     x = d_in[lo * C:].cpu().numpy().reshape(-1, C).astype(np.float64)
     want = O.Fir(taps, C).process(x).reshape(-1, C)[N:].astype(np.float32)
     assert np.array_equal(y_ref[(lo + N) * C:].cpu().numpy().reshape(-1, C), want)
+    # ... and the overlap-save output ITSELF against the oracle (not only through the direct form):
+    # the head of the stream (zero history, the Line's first tiles), a window in the middle, and
+    # the last frames (byte offsets at the top of / beyond 32 bits for K = 131072)
+    W = 6000
+    frames_total = n // C
+    for start in (0, (frames_total // 2 // 769) * 769 - 1000, frames_total - W):
+        xs = d_in[start * C:(start + W) * C].cpu().numpy().reshape(-1, C).astype(np.float64)
+        w64 = O.Fir(taps, C).process(xs).reshape(-1, C)
+        skip = 0 if start == 0 else N          # a window inside the stream needs N-1 frames of run-in
+        g = y_ols[(start + skip) * C:(start + W) * C].cpu().numpy().reshape(-1, C)
+        d = ulp_diff_f32(g, w64[skip:], floor)
+        assert d.max() <= 1.0, f"ols vs oracle at frame {start}: {d.max()} ulp"
+        assert np.mean(g != w64[skip:].astype(np.float32)) < 1e-3
 
 
 def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
@@ -219,6 +232,8 @@ def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
     (37, 2, 9_000, 33),            # many short Lines: most tiles are a Line's first (history) tile
     (2, 64, 12_345, 512),          # the channel limit and the longest supported filter
     (5, 5, 7_777, 16),             # odd channel count (scalar-pair path), shortest supported filter
+    (64, 2, 64 * 4096, 256),       # BASELINE configs[2] at full size: 64 Lines x 64 buffers of 4096 x 2
+    (512, 8, 4096, 256),           # BASELINE configs[3] at full size: 512 Lines x 8 ch x one 4096 buffer
 ])
 def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
     # every (Line, channel pair, tile) item must be produced exactly once whatever the grid,
@@ -251,3 +266,8 @@ def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
     d = ulp_diff_f32(got, ref.astype(np.float64), floor)
     assert d.max() <= 1.0, float(d.max())
     assert np.mean(got != ref) < 1e-3
+    # spot Lines against the oracle itself (first, one in the middle, last), both forms
+    for l in sorted({0, lines // 2, lines - 1}):
+        want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(frames, channels)
+        assert np.array_equal(ref[l], want.astype(np.float32)), f"direct form, line {l}"
+        assert ulp_diff_f32(got[l], want, floor).max() <= 1.0, f"overlap-save form, line {l}"
