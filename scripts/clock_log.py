@@ -20,9 +20,12 @@ import time
 
 def find_nodes():
     nodes = {}
-    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-        if not os.path.exists(os.path.join(card, "pp_dpm_sclk")):
-            continue
+    cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+             if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+    # several cards in sysfs, one visible to HIP: CLOCK_LOG_CARD picks it (index into `cards`)
+    pick = int(os.environ.get("CLOCK_LOG_CARD", "0"))
+    nodes["cards"] = cards
+    for card in cards[pick:pick + 1]:
         nodes["card"] = card
         nodes["sclk"] = os.path.join(card, "pp_dpm_sclk")
         nodes["mclk"] = os.path.join(card, "pp_dpm_mclk")
