@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpipe_hip.so")
+# PIPE_HIP_LIB: an alternative build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("PIPE_HIP_LIB") or os.path.join(_HERE, "lib", "libpipe_hip.so")
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE = range(7)
 F32, F64 = 0, 1

@@ -545,7 +545,8 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
     // the 32 x 32 decomposition (one transform per half-wave, fir_ols32.hip): even channel counts
-    static const int variant = std::getenv("PIPE_HIP_OLS_VARIANT") ? std::atoi(std::getenv("PIPE_HIP_OLS_VARIANT")) : 16;
+    // (default; PIPE_HIP_OLS_VARIANT=16 selects the 16 x 16 x 4 kernel of this file for A/B runs)
+    static const int variant = std::getenv("PIPE_HIP_OLS_VARIANT") ? std::atoi(std::getenv("PIPE_HIP_OLS_VARIANT")) : 32;
     if (vec && variant == 32)
         return run_ols32(*impl_, d_in, in_dtype, d_out, out_dtype, hist, hist_new, frames, channels, lines, s,
                          kernel_name, timer);

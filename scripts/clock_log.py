@@ -22,7 +22,9 @@ def find_nodes():
     nodes = {}
     cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
              if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
-    # several cards in sysfs, one visible to HIP: CLOCK_LOG_CARD picks it (index into `cards`)
+    # several cards in sysfs, one visible to HIP: CLOCK_LOG_CARD picks it (index into `cards`);
+    # default: the card with the highest power reading right now is unlikely to be right either,
+    # so main() samples EVERY card and reports the one whose power moved most
     pick = int(os.environ.get("CLOCK_LOG_CARD", "0"))
     nodes["cards"] = cards
     for card in cards[pick:pick + 1]:
@@ -67,8 +69,44 @@ def main():
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
     nodes = find_nodes()
+    if "CLOCK_LOG_CARD" not in os.environ and len(nodes.get("cards", [])) > 1:
+        # probe: run nothing, look at every card for ~0.3 s while a tiny HIP job spins?  Simpler:
+        # sample all cards during the command and keep the one with the largest power swing.
+        all_nodes = []
+        for i in range(len(nodes["cards"])):
+            os.environ["CLOCK_LOG_CARD"] = str(i)
+            all_nodes.append(find_nodes())
+        del os.environ["CLOCK_LOG_CARD"]
+    else:
+        all_nodes = [nodes]
     samples = []
     stop = threading.Event()
+
+    per_card = [[] for _ in all_nodes]
+
+    def sample_one(nodes):
+        s = {"t": time.time()}
+        if "freq1_input" in nodes:
+            v = read(nodes["freq1_input"])
+            s["sclk_mhz"] = float(v) / 1e6 if v else None
+        else:
+            s["sclk_mhz"] = starred_mhz(read(nodes.get("sclk", "")))
+        s["mclk_mhz"] = starred_mhz(read(nodes.get("mclk", "")))
+        for k in ("power1_average", "power1_input"):
+            if k in nodes:
+                v = read(nodes[k])
+                s["power_w"] = float(v) / 1e6 if v else None
+                break
+        if "busy" in nodes:
+            v = read(nodes["busy"])
+            s["busy"] = float(v) if v and v.strip() else None
+        return s
+
+    def sampler_all():
+        while not stop.is_set():
+            for i, nd in enumerate(all_nodes):
+                per_card[i].append(sample_one(nd))
+            time.sleep(a.period)
 
     def sampler():
         while not stop.is_set():
@@ -98,7 +136,7 @@ def main():
             return f"rocm-smi unavailable: {e}"
 
     before = smi()
-    th = threading.Thread(target=sampler, daemon=True)
+    th = threading.Thread(target=sampler_all if len(all_nodes) > 1 else sampler, daemon=True)
     th.start()
     t0 = time.time()
     rc = subprocess.call(cmd)
@@ -106,6 +144,15 @@ def main():
     stop.set()
     th.join(timeout=1)
     after = smi()
+    if len(all_nodes) > 1:
+        def swing(lst):
+            p = [x["power_w"] for x in lst if x.get("power_w") is not None]
+            return (max(p) - min(p)) if p else 0.0
+        best = max(range(len(all_nodes)), key=lambda i: swing(per_card[i]))
+        samples = per_card[best]
+        nodes = all_nodes[best]
+        nodes["picked_card_index"] = best
+        nodes["power_swing_w_per_card"] = [round(swing(c), 1) for c in per_card]
 
     def dist(key, busy_only=True):
         vals = [s[key] for s in samples if s.get(key) is not None and (not busy_only or (s.get("busy") or 0) > 0

@@ -1,8 +1,12 @@
 #!/bin/bash
-# Same-box A/B of two builds of libpipe_hip.so at steady state (scripts/gpu_steady.sh):
-#   cp pipe_amd/lib/libpipe_hip.so pipe_amd/lib/libpipe_hip_old.so   (before the change)
-#   cp pipe_amd/lib/libpipe_hip.so pipe_amd/lib/libpipe_hip_new.so   (after it)
-#   gpurun -- 'bash scripts/gpu_ab.sh'
-cp pipe_amd/lib/libpipe_hip.so /tmp/orig.so
-for v in old new old new; do cp pipe_amd/lib/libpipe_hip_$v.so pipe_amd/lib/libpipe_hip.so; TAG=$v bash scripts/gpu_steady.sh | tail -1; done
-cp /tmp/orig.so pipe_amd/lib/libpipe_hip.so
+# A/B bench of environment-selected kernel variants, interleaved, 3 rounds:
+#   scripts/gpu_ab.sh "ENV1" "ENV2" ...
+set -u
+export TMPDIR=/tmp
+for rep in 1 2 3; do
+for e in "$@"; do
+  env $e python bench.py --no-cpu-baseline --steps ${AB_STEPS:-150} --warmup 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('[$e]', r['kernel'], 'ms', r['avg_kernel_ms'], 'frac', r['frac'])"
+done; done
