@@ -388,7 +388,7 @@ int pipe_hip_flush(pipe_hip_processor *p)
     PH_TRY(p->select_device());
     PH_HIP(hipStreamSynchronize(p->stream));
     p->in_flight = false;
-    return PIPE_HIP_OK;
+    return p->poll_error();
 }
 
 int pipe_hip_destroy(pipe_hip_processor *p)

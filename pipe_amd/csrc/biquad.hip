@@ -643,6 +643,17 @@ public:
         return PIPE_HIP_OK;
     }
 
+    bool fuse_view_biquad(BiquadFuseView *v) override
+    {
+        if (windowed())
+            return false;
+        v->state = static_cast<double *>(state_.p);
+        v->coeffs = &q_.c[0][0];
+        v->sections = S_;
+        v->relaxed = !exact_ && !env_exact_;
+        return true;
+    }
+
     // The LDS-staged exact kernel runs one workgroup per Line: it wins when Lines are few enough
     // that the register form cannot fill its waves anyway (always the case for the per-buffer
     // ProcessFunc form); with thousands of series the register form's 64 busy lanes per wave do.

@@ -4,6 +4,9 @@
 // Only the first stage reads, and only the last stage writes, buffers of the
 // handle's I/O dtype -- so a float32 chain rounds once, at the end, exactly like
 // `(float)` applied to the oracle's float64 chain.
+#include <cstdlib>
+
+#include "chain_fused.hpp"
 #include "common.hpp"
 
 namespace pipehip {
@@ -36,6 +39,26 @@ public:
         const void *src = d_in;
         int src_dtype = in_dtype;
         const size_t ns = stages.size();
+        // FIR -> biquad (-> gain) on float32 buffers, a call large enough for the overlap-save
+        // form: ONE kernel, one read and one write of the buffers (chain_fused.hip)
+        if (fusable(d_in, in_dtype, d_out, out_dtype, frames)) {
+            FirFuseView fv{};
+            BiquadFuseView bv{};
+            double g = 1.0;
+            const bool has_gain = ns == 3 && gain_value(stages[2].get(), &g);
+            if (stages[0]->fuse_view_fir(&fv) && stages[1]->fuse_view_biquad(&bv) && fv.relaxed && bv.relaxed &&
+                bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
+                const int64_t L = 1025 - fv.ntaps;
+                const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
+                if (items >= fv.min_items) {
+                    if (!fused_)
+                        fused_.reset(new fused::Plan());
+                    PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, frames, cfg.channels, cfg.lines, s, &timer,
+                                       &last_kernel));
+                    return stages[0]->fuse_commit_fir(s);
+                }
+            }
+        }
         PH_TRY(timer.begin(s));
         int hop = 0;
         for (size_t i = 0; i < ns; ++i) {
@@ -87,6 +110,7 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
+    int poll_error() override { return fused_ ? fused_->poll_error(stream) : PIPE_HIP_OK; }
     int set_stage_param(int32_t stage, int32_t param, const double *values, int32_t count) override
     {
         if (stage < 0 || (size_t)stage >= stages.size())
@@ -95,7 +119,24 @@ public:
     }
 
 private:
+    bool fusable(const void *d_in, int in_dtype, const void *d_out, int out_dtype, int64_t frames) const
+    {
+        if (!fused::Plan::enabled() || windowed() || frames <= 0)
+            return false;
+        if (stages.size() != 2 && stages.size() != 3)
+            return false;
+        if (in_dtype != PIPE_HIP_F32 || out_dtype != PIPE_HIP_F32 || cfg.channels % 2 != 0)
+            return false;
+        if (stages.size() == 3) {
+            double g;
+            if (!gain_value(stages[2].get(), &g))
+                return false;
+        }
+        return reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    }
+
     DevBuf tmp_[2];
+    std::unique_ptr<fused::Plan> fused_;
 };
 
 }  // namespace

@@ -1,0 +1,36 @@
+// The fused FIR -> biquad -> gain kernel of a chain (chain_fused.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace pipehip {
+namespace fused {
+
+constexpr int kMaxFusedSections = 2;
+
+class Plan {
+public:
+    struct Impl;
+    Plan();
+    ~Plan();
+    Plan(const Plan &) = delete;
+    Plan &operator=(const Plan &) = delete;
+
+    static bool enabled();  // PIPE_HIP_CHAIN_FUSED=0 switches the fused form off
+    // One launch: every Line advances by `frames` frames through FIR -> biquad (-> gain).
+    // float32 buffers, even channel count, 16-byte aligned pointers (the caller checks).
+    int run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_processor::BiquadFuseView &bq, bool has_gain,
+            double gain, const void *d_in, void *d_out, int64_t frames, int channels, int lines, hipStream_t s,
+            KernelTimer *timer, const char **kernel_name);
+    // EHIP if a launch since the last poll gave up waiting for a predecessor tile
+    int poll_error(hipStream_t s);
+
+private:
+    int prepare(const double *coeffs, int S, int ntaps, hipStream_t s);
+    Impl *impl_;
+};
+
+}  // namespace fused
+}  // namespace pipehip

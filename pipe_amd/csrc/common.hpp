@@ -203,6 +203,29 @@ struct pipe_hip_processor {
         return PIPE_HIP_EINVAL;
     }
 
+    // ---- hooks of the fused chain kernel (chain_fused.hip) --------------------------------
+    // A FIR stage with an overlap-save plan / a biquad stage hand out what the fused kernel
+    // needs; everything else answers false and the chain runs its stages one after the other.
+    struct FirFuseView {
+        const double *hist;    // current history of all Lines
+        double *hist_new;      // the half the launch writes
+        const void *plan;      // ols::Plan::Impl
+        int ntaps;
+        bool relaxed;          // the stage may use a form that is not bit-exact
+        int64_t min_items;     // smallest call (in FFT items) that takes the overlap-save form
+    };
+    struct BiquadFuseView {
+        double *state;         // [lines][C][S][2]
+        const double *coeffs;  // [S][5], host
+        int sections;
+        bool relaxed;
+    };
+    virtual bool fuse_view_fir(FirFuseView *) { return false; }
+    virtual int fuse_commit_fir(hipStream_t) { return PIPE_HIP_EINVAL; }  // the launch wrote hist_new
+    virtual bool fuse_view_biquad(BiquadFuseView *) { return false; }
+    // device-side failures that cannot be reported by the asynchronous call that caused them
+    virtual int poll_error() { return PIPE_HIP_OK; }
+
     int init_common(const pipe_hip_config *c);
     int ensure_staging();
     int select_device() const;

@@ -480,6 +480,20 @@ public:
         return flip_history(s);
     }
 
+    bool fuse_view_fir(FirFuseView *v) override
+    {
+        if (!ols_ || windowed())
+            return false;
+        v->hist = static_cast<const double *>(hist_[cur_hist_].p);
+        v->hist_new = hist_next();
+        v->plan = &ols_->impl();
+        v->ntaps = N_;
+        v->relaxed = !exact_;
+        v->min_items = ols_min_items();
+        return true;
+    }
+    int fuse_commit_fir(hipStream_t s) override { return flip_history(s); }
+
 private:
     // enough 1024-point transforms to give every SIMD of the chip a few
     int64_t ols_min_items() const

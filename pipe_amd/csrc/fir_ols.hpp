@@ -28,6 +28,8 @@ public:
             int64_t frames,
             int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer = nullptr);
 
+    const Impl &impl() const { return *impl_; }
+
 private:
     Impl *impl_;
 };

@@ -1,0 +1,123 @@
+"""The fused FIR -> biquad -> gain kernel (chain_fused.hip): one pass over float32 buffers,
+tile-to-tile biquad state through decoupled look-back.
+
+Contract (the same as the overlap-save FIR and the time-segmented biquad it replaces in a
+chain): the float64 value differs from the oracle's ordered arithmetic by O(1e-16) of full
+scale, so the float32 result is the oracle's rounded value except at rounding boundaries:
+    |gpu - (float)oracle| <= 1 ulp_f32( max(|oracle|, 2^-24 * max|oracle of the Line|) )
+and almost every sample is identical.  PIPE_HIP_PARAM_EXACT keeps the staged bit-exact chain."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P = None
+torch = None
+
+
+def setup_module(module):
+    global P, torch
+    import torch as _t
+    from pipe_amd import processors as _p
+    assert _t.cuda.is_available()
+    P, torch = _p, _t
+
+
+def ulps(got, want64):
+    floor = 2.0 ** -24 * np.abs(want64).max()
+    want32 = want64.astype(np.float32)
+    mag = np.maximum(np.abs(want64), floor).astype(np.float32)
+    return np.abs(got.astype(np.float64) - want32.astype(np.float64)) / np.spacing(mag).astype(np.float64)
+
+
+DC_BLOCK = np.array([[1.0, -1.0, 0.0, -0.9995, 0.0]])             # pole at 0.9995: forgets over ~10^4 frames
+LOWPASS = synth.biquad_rbj_lowpass()                              # forgets within one 769-frame tile
+TWO_SECTIONS = np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0)])
+
+
+def run_chain(taps, q, g, x, calls, exact=False):
+    """x: (lines, frames, C) float32; calls: frame counts of consecutive process_batch calls."""
+    lines, frames, C = x.shape
+    kw = dict(dtype=np.float32, lines=lines, max_batch=1)
+    fir = P.Fir(taps, frames, C, **kw)
+    stages = [fir, P.Biquad(q, frames, C, **kw)]
+    if g is not None:
+        stages.append(P.Gain(g, frames, C, **kw))
+    with P.Chain(stages) as p:
+        if exact:
+            p._set_param(3, [1.0])
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        outs, names, pos = [], [], 0
+        for n in calls:
+            xin = d_in[:, pos:pos + n, :].contiguous()
+            y = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, y, n)
+            torch.cuda.synchronize()
+            names.append(p.kernel_name())
+            outs.append(y)
+            pos += n
+        p.flush()   # reports a look-back that gave up
+        return torch.cat(outs, dim=1).cpu().numpy(), names
+
+
+def oracle_chain(taps, q, g, x):
+    C = x.shape[-1]
+    y = O.Biquad(q, C).process(O.Fir(taps, C).process(x.astype(np.float64)))
+    return (O.gain(y, g) if g is not None else y).reshape(-1, C)
+
+
+@pytest.mark.parametrize("lines,C,frames,ntaps,q,g,calls", [
+    (24, 8, 4096, 256, LOWPASS, 0.7071067811865476, [4096]),           # BASELINE configs[3] shape, fewer Lines
+    (1, 2, 769 * 300 + 17, 256, LOWPASS, 0.5, [769 * 100, 769 * 200 + 17]),   # one long series, two calls
+    (1, 2, 769 * 90, 256, DC_BLOCK, None, [769 * 90]),                 # slow filter: look-back goes to a P record
+    (3, 4, 50_000, 100, DC_BLOCK, 1.25, [20_000, 30_000]),             # several windows of 32 predecessors, ragged
+    (5, 6, 30_000, 64, TWO_SECTIONS, 0.9, [9_999, 20_001]),            # 2 sections, 3 pairs (units straddle tiles)
+    (2, 2, 40_000, 511, TWO_SECTIONS, None, [40_000]),                 # longest filter: tiles of 514 frames
+    (7, 16, 5_000, 16, LOWPASS, 2.0, [5_000]),                         # shortest filter, first output in lane 0
+])
+def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, calls, monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    rng = np.random.default_rng(7 + lines * 31 + C)
+    x = rng.uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
+    got, names = run_chain(taps, q, g, x, calls)
+    assert all("chain_fused_kernel" in n for n in names), names
+    assert not np.isnan(got).any()
+    worst, differ = 0.0, 0
+    for l in sorted({0, lines // 2, lines - 1}):
+        want = oracle_chain(taps, q, g, x[l])
+        d = ulps(got[l], want)
+        worst = max(worst, float(d.max()))
+        differ += int((got[l] != want.astype(np.float32)).sum())
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at frame {np.argmax(d) // C}"
+    assert differ <= max(4, frames * C * 3 // 100_000), differ
+
+
+def test_exact_mode_keeps_the_staged_bit_exact_chain(monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, frames, ntaps = 4, 4, 8192, 128
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    x = np.random.default_rng(3).uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
+    got, names = run_chain(taps, LOWPASS, 0.5, x, [frames], exact=True)
+    assert all("chain_fused" not in n for n in names), names
+    for l in range(lines):
+        assert np.array_equal(got[l], oracle_chain(taps, LOWPASS, 0.5, x[l]).astype(np.float32))
+
+
+def test_full_config3_shape_spot_lines(monkeypatch):
+    # BASELINE configs[3] at full size: 512 Lines x 8 ch x 4096 frames, FIR-256 -> biquad -> gain
+    lines, C, frames, ntaps = 512, 8, 4096, 256
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    g = 0.7071067811865476
+    x = np.stack([synth.samples(synth.line_seed(900 + l), 0, frames * C, np.float32).reshape(frames, C)
+                  for l in range(lines)])
+    got, names = run_chain(taps, LOWPASS, g, x, [frames])
+    assert all("chain_fused_kernel" in n for n in names), names
+    assert not np.isnan(got).any()
+    for l in (0, 1, 170, 171, 255, 340, 511):
+        d = ulps(got[l], oracle_chain(taps, LOWPASS, g, x[l]))
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
