@@ -48,7 +48,7 @@ public:
             const bool has_gain = ns == 3 && gain_value(stages[2].get(), &g);
             if (stages[0]->fuse_view_fir(&fv) && stages[1]->fuse_view_biquad(&bv) && fv.relaxed && bv.relaxed &&
                 bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
-                const int64_t L = 1025 - fv.ntaps;
+                const int64_t L = 1024 - (fv.ntaps - 1 + 31) / 32 * 32;
                 const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
                 if (items >= fv.min_items) {
                     if (!fused_)

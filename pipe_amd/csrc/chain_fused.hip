@@ -85,13 +85,6 @@ Mat one_step(const double *c, int S)
     }
     return r;
 }
-template <int N>
-void store(double (&dst)[N][N], const Mat &m)
-{
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j)
-            dst[i][j] = (double)m.m[i][j];
-}
 void store_flat(double *dst, const Mat &m)
 {
     for (int i = 0; i < m.n; ++i)
@@ -99,10 +92,83 @@ void store_flat(double *dst, const Mat &m)
             dst[i * m.n + j] = (double)m.m[i][j];
 }
 
+// The state after a Line's LAST frame.  The fused kernel leaves the true start state of the
+// 32-position segment that holds that frame (seg_state); here one half-wave per (Line, channel)
+// series stages the segment's input window in LDS, computes the FIR output of its <= 32 frames
+// in the direct form (the oracle's own ordered sum, one frame per lane, taps as scalar operands)
+// and walks the recurrence over them.  Runs behind the fused kernel on the same stream, so it
+// writes the biquad stage's state array itself.
+struct TailArgs {
+    int64_t frames, line_stride;
+    int C, N, H, HP, L, tiles_per_line, nseries;  // nseries = lines * C
+    const double *seg_state;                       // [lines][pairs][2][2S]
+    double *state;                                 // [lines][C][2S]: the biquad stage's own
+};
+constexpr int kTailSeries = 8;  // series (half-waves) per workgroup
+typedef const __attribute__((address_space(4))) double *tail_const_f64;
+template <int S>
+__global__ void __launch_bounds__(32 * kTailSeries)
+chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ hist_base,
+                  const double *__restrict__ taps, const TailArgs a, const FuseConst<S> fc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    constexpr int N2 = 2 * S;
+    const int local = threadIdx.x >> 5, l5 = threadIdx.x & 31;
+    const int sid = (int)blockIdx.x * kTailSeries + local;
+    const int wlen = 32 + a.H;  // window: frames f0 - H .. f0 + 31
+    double *xs = reinterpret_cast<double *>(tail_smem) + (size_t)local * wlen;
+    const bool live = sid < a.nseries;
+    const int line = live ? sid / a.C : 0, ch = live ? sid - line * a.C : 0;
+    const int tile = a.tiles_per_line - 1;
+    const int64_t t0 = (int64_t)tile * a.L;
+    const int len = (int)(a.frames - t0);
+    const int plast = a.HP + len - 1, kl = plast >> 5, jl = plast & 31;
+    const int64_t f0 = t0 + 32 * kl - a.HP;  // first frame of the segment
+    if (live) {
+        const float *__restrict__ in = in_base + (int64_t)line * a.line_stride + ch;
+        const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
+        for (int i = l5; i < wlen; i += 32) {
+            const int64_t g = f0 - a.H + i;
+            double v = 0.0;
+            if (g >= 0) {
+                if (g < a.frames)
+                    v = (double)in[g * a.C];
+            } else if (g >= -(int64_t)a.H) {
+                v = hist[(g + a.H) * a.C];
+            }
+            xs[i] = v;
+        }
+    }
+    __syncthreads();
+    if (!live)
+        return;
+    // FIR output of frame f0 + l5: acc = fma(h[k], x[f - k], acc), k = 0..N-1
+    double y = 0.0;
+    {
+        const double *w = xs + a.H + l5;
+        const tail_const_f64 h = (tail_const_f64)taps;
+        for (int k = 0; k < a.N; ++k)
+            y = __builtin_fma(h[k], w[-k], y);
+    }
+    double st[N2];
+    const double *sp = a.seg_state + ((int64_t)(line * (a.C / 2) + ch / 2) * 2 + (ch & 1)) * N2;
+#pragma unroll
+    for (int j = 0; j < N2; ++j)
+        st[j] = sp[j];
+    for (int c = 0; c <= jl; ++c)
+        (void)ols::biquad_step<S>(__shfl(y, c, 32), st, fc);
+    if (l5 == 0) {
+        double *dst = a.state + (int64_t)sid * N2;
+#pragma unroll
+        for (int j = 0; j < N2; ++j)
+            dst[j] = st[j];
+    }
+}
+
 }  // namespace
 
 struct Plan::Impl {
-    DevBuf rec, tj, pk, state_out, err;
+    DevBuf rec, mats, seg_state, err, prof;
     PinnedBuf h_tab;  // staging of the two tables
     std::vector<double> coeffs;
     int S = 0, H = -1;
@@ -129,28 +195,17 @@ bool Plan::enabled()
     return on;
 }
 
-template <int S>
-static void fill_const(FuseConst<S> *fc, const double *coeffs, const Mat &M, int L, const Mat &ML, const Mat &T32, int D)
-{
-    std::memcpy(fc->c, coeffs, sizeof(double) * 5 * S);
-    for (int i = 0; i < 5; ++i)
-        store(fc->A[i], power(M, 32L << i));
-    (void)L;
-    store(fc->ML, ML);
-    store(fc->T32, T32);
-    fc->D = D;
-}
-
 // (re)build everything that depends on the coefficients or the tap count
 int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
 {
     Impl &I = *impl_;
-    const int H = ntaps - 1, L = ols::kM32 - H;
+    const int H = (ntaps - 1 + 31) / 32 * 32, L = ols::kM32 - H;  // (the padded history: Plan::run)
     if (I.S == S && I.H == H && I.coeffs.size() == (size_t)5 * S &&
         std::memcmp(I.coeffs.data(), coeffs, sizeof(double) * 5 * S) == 0)
         return PIPE_HIP_OK;
     const int n = 2 * S;
     const Mat M = one_step(coeffs, S);
+    const Mat M32 = power(M, 32);
     const Mat ML = power(M, L);
     std::vector<Mat> T(33);
     T[0] = identity(n);
@@ -163,20 +218,21 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
         for (int i = 0; i < n; ++i)
             for (int k = 0; k < n; ++k)
                 big = std::fmax(big, std::fabs(T[j].m[i][k]));
-        if (big < 0x1p-90L)
+        if (big < 0x1p-60L)
             D = j;
     }
     I.D = D;
-    if (S == 1)
-        fill_const<1>(&I.c1, coeffs, M, L, ML, T[32], D);
-    else
-        fill_const<2>(&I.c2, coeffs, M, L, ML, T[32], D);
-    // tables: Tj [33][n][n], Pk [32][n][n]
-    const size_t tj_n = (size_t)33 * n * n, pk_n = (size_t)32 * n * n;
-    if (!I.tj.p) {
-        PH_TRY(I.tj.alloc(sizeof(double) * 33 * kMaxN2 * kMaxN2));
-        PH_TRY(I.pk.alloc(sizeof(double) * 32 * kMaxN2 * kMaxN2));
-        PH_TRY(I.h_tab.alloc(sizeof(double) * 65 * kMaxN2 * kMaxN2));
+    if (S == 1) {
+        std::memcpy(I.c1.c, coeffs, sizeof(double) * 5);
+        I.c1.D = D;
+    } else {
+        std::memcpy(I.c2.c, coeffs, sizeof(double) * 10);
+        I.c2.D = D;
+    }
+    const size_t bytes = sizeof(double) * ols::kMatCount * kMaxN2 * kMaxN2;
+    if (!I.mats.p) {
+        PH_TRY(I.mats.alloc(bytes));
+        PH_TRY(I.h_tab.alloc(bytes));
         PH_TRY(I.err.alloc(sizeof(int)));
         PH_HIP(hipMemsetAsync(I.err.p, 0, sizeof(int), s));
     } else {
@@ -184,13 +240,20 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
         PH_HIP(hipStreamSynchronize(s));
     }
     double *h = static_cast<double *>(I.h_tab.p);
+    const size_t mm = (size_t)n * n;
+    Mat ak = identity(n);
+    for (int j = 0; j <= 16; ++j) {
+        store_flat(h + (ols::kMatAk + j) * mm, ak);
+        ak = mul(ak, M32);
+    }
+    store_flat(h + ols::kMatML * mm, ML);
+    store_flat(h + ols::kMatT32 * mm, T[32]);
     for (int j = 0; j <= 32; ++j)
-        store_flat(h + (size_t)j * n * n, T[j]);
+        store_flat(h + (ols::kMatTj + j) * mm, T[j]);
     const int k0 = H / 32;
     for (int k = 0; k < 32; ++k)
-        store_flat(h + tj_n + (size_t)k * n * n, k > k0 ? power(M, 32L * k - H) : identity(n));
-    PH_HIP(hipMemcpyAsync(I.tj.p, h, sizeof(double) * tj_n, hipMemcpyHostToDevice, s));
-    PH_HIP(hipMemcpyAsync(I.pk.p, h + tj_n, sizeof(double) * pk_n, hipMemcpyHostToDevice, s));
+        store_flat(h + (ols::kMatPk + k) * mm, k > k0 ? power(M, 32L * (k - k0)) : identity(n));
+    PH_HIP(hipMemcpyAsync(I.mats.p, h, sizeof(double) * ols::kMatCount * mm, hipMemcpyHostToDevice, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);
     I.S = S;
     I.H = H;
@@ -215,11 +278,11 @@ int Plan::poll_error(hipStream_t s)
     return PIPE_HIP_OK;
 }
 
-template <int S>
+template <int S, bool GENERAL>
 static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const double *hist, Args32 a, const FuseArgs &fa,
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
 {
-    auto kfn = ols::fir_ols32_kernel<float, float, S>;
+    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL>;
     const size_t lds =
         sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) + sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -239,6 +302,31 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
                           static_cast<float *>(d_out), hist, static_cast<const double2 *>(P.tw32.p),
                           static_cast<const double2 *>(P.hperm[P.cur].p), a, fa, fc);
     PH_HIP(hipGetLastError());
+#ifdef PH_FUSE_PROF
+    {
+        static int launches = 0;
+        if (++launches == 30 && fa.prof) {
+            PH_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h((size_t)ols::kFuseProfPhases * kWaves32 * grid);
+            PH_HIP(hipMemcpy(h.data(), fa.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            static const char *names[ols::kFuseProfPhases] = {
+                "window + FIR transform", "to segments + pass 1", "scan", "publish A", "look-back", "publish P",
+                "pass 3", "back to natural", "last-tile pass 3 + back", "stores"};
+            double sum[ols::kFuseProfPhases] = {}, tot = 0;
+            for (size_t w = 0; w < (size_t)kWaves32 * grid; ++w)
+                for (int i = 0; i < ols::kFuseProfPhases; ++i)
+                    sum[i] += (double)h[w * ols::kFuseProfPhases + i];
+            for (double v : sum)
+                tot += v;
+            std::fprintf(stderr, "[fused prof] s_memtime ticks per unit (wave time), %lld units, grid %u\n",
+                         (long long)a.nunits, grid);
+            for (int i = 0; i < ols::kFuseProfPhases; ++i)
+                std::fprintf(stderr, "[fused prof]   %-26s %9.1f  %5.1f %%\n", names[i], sum[i] / (double)a.nunits,
+                             100.0 * sum[i] / tot);
+            std::fprintf(stderr, "[fused prof]   %-26s %9.1f\n", "total", tot / (double)a.nunits);
+        }
+    }
+#endif
     return PIPE_HIP_OK;
 }
 
@@ -257,7 +345,8 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     a.C = channels;
     a.N = fir.ntaps;
     a.H = fir.ntaps - 1;
-    a.L = ols::kM32 - a.H;
+    a.HP = (a.H + 31) / 32 * 32;  // a tile's first output opens a segment (ols32_kernel.hpp)
+    a.L = ols::kM32 - a.HP;
     a.pairs = channels / 2;
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
@@ -274,38 +363,78 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         PH_HIP(hipMemsetAsync(I.rec.p, 0, sizeof(unsigned long long) * need, s));
         I.rec_granules = need;
     }
-    const size_t state_bytes = sizeof(double) * (size_t)lines * channels * N2;
-    if (I.state_out.bytes < state_bytes)
-        PH_TRY(I.state_out.alloc(state_bytes));
     if (++I.epoch == 0) {  // 2^32 launches: tags would repeat
         PH_HIP(hipMemsetAsync(I.rec.p, 0, sizeof(unsigned long long) * I.rec_granules, s));
         I.epoch = 1;
     }
     FuseArgs fa{};
-    fa.k0 = a.H / 32;
-    fa.n00 = a.H % 32;
+    fa.k0 = a.HP / 32;
     fa.epoch = I.epoch;
     fa.rec = static_cast<unsigned long long *>(I.rec.p);
     fa.state = bq.state;
-    fa.state_out = static_cast<double *>(I.state_out.p);
-    fa.Tj = static_cast<const double *>(I.tj.p);
-    fa.Pk = static_cast<const double *>(I.pk.p);
+    const size_t seg_bytes = sizeof(double) * (size_t)lines * a.pairs * NV;
+    if (I.seg_state.bytes < seg_bytes)
+        PH_TRY(I.seg_state.alloc(seg_bytes));
+    fa.seg_state = static_cast<double *>(I.seg_state.p);
+    fa.mats = static_cast<const double *>(I.mats.p);
     fa.err = static_cast<int *>(I.err.p);
+#ifdef PH_FUSE_PROF
+    if (!I.prof.p)
+        PH_TRY(I.prof.alloc(sizeof(unsigned long long) * ols::kFuseProfPhases * kWaves32 * 4096));
+    fa.prof = static_cast<unsigned long long *>(I.prof.p);
+#endif
     I.err_checked = false;
     I.last_stream = s;
+    // a filter that forgets within one look-back window (D <= 32) takes the kernel without P
+    // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
+    static const bool force_general = std::getenv("PIPE_HIP_CHAIN_GENERAL") != nullptr;
+    const bool general = force_general || I.D > 32;
     if (S == 1) {
-        I.c1.has_gain = has_gain ? 1 : 0;
-        I.c1.gain = gain;
-        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
-        PH_TRY(launch<1>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer));
+        I.c1.gain = has_gain ? gain : 1.0;
+        if (general) {
+            I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
+            PH_TRY((launch<1, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        } else {
+            I.c1.D = I.D;
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
+            PH_TRY((launch<1, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        }
     } else {
-        I.c2.has_gain = has_gain ? 1 : 0;
-        I.c2.gain = gain;
-        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
-        PH_TRY(launch<2>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer));
+        I.c2.gain = has_gain ? gain : 1.0;
+        if (general) {
+            I.c2.D = force_general && I.D <= 32 ? I.D : (1 << 30);
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain,general>";
+            PH_TRY((launch<2, true>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+        } else {
+            I.c2.D = I.D;
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
+            PH_TRY((launch<2, false>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+        }
     }
-    // the biquad stage's own state <- the state after this call (stream-ordered)
-    PH_HIP(hipMemcpyAsync(bq.state, I.state_out.p, state_bytes, hipMemcpyDeviceToDevice, s));
+    {   // the state after every Line's last frame
+        TailArgs ta{};
+        ta.frames = frames;
+        ta.line_stride = a.line_stride;
+        ta.C = channels;
+        ta.N = a.N;
+        ta.H = a.H;
+        ta.HP = a.HP;
+        ta.L = a.L;
+        ta.tiles_per_line = a.tiles_per_line;
+        ta.nseries = lines * channels;
+        ta.seg_state = static_cast<const double *>(I.seg_state.p);
+        ta.state = bq.state;
+        const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
+        const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
+        if (S == 1)
+            hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c1);
+        else
+            hipLaunchKernelGGL(chain_tail_kernel<2>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c2);
+        PH_HIP(hipGetLastError());
+    }
     return PIPE_HIP_OK;
 }
 

@@ -210,6 +210,7 @@ struct pipe_hip_processor {
         const double *hist;    // current history of all Lines
         double *hist_new;      // the half the launch writes
         const void *plan;      // ols::Plan::Impl
+        const double *taps;    // float64 taps on the device (the direct form's copy)
         int ntaps;
         bool relaxed;          // the stage may use a form that is not bit-exact
         int64_t min_items;     // smallest call (in FFT items) that takes the overlap-save form

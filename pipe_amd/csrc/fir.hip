@@ -487,6 +487,7 @@ public:
         v->hist = static_cast<const double *>(hist_[cur_hist_].p);
         v->hist_new = hist_next();
         v->plan = &ols_->impl();
+        v->taps = static_cast<const double *>(taps_[cur_taps_].p);
         v->ntaps = N_;
         v->relaxed = !exact_;
         v->min_items = ols_min_items();

@@ -84,7 +84,8 @@ int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, 
     a.C = channels;
     a.N = I.N;
     a.H = I.N - 1;
-    a.L = kM - a.H;
+    a.HP = a.H;
+    a.L = kM - a.HP;
     a.pairs = channels / 2;
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);

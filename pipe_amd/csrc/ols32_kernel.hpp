@@ -3,6 +3,8 @@
 // (chain_fused.hip).  Included by both files; each instantiates what it launches.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -13,13 +15,37 @@ namespace pipehip {
 namespace ols {
 
 constexpr int kWaves32 = 8;             // waves per workgroup = per CU
+
+// -DPH_FUSE_PROF: per-phase s_memtime sums of every wave of the fused kernel (a debug build of
+// the library, scripts/build_prof_lib.sh; never the shipped one)
+#ifdef PH_FUSE_PROF
+constexpr int kFuseProfPhases = 10;
+#define PH_FSTAMP(i)                                                          \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        fprof_acc[(i)] += now_ - fprof_last;                                  \
+        fprof_last = now_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
+#define PH_FPROF_PARAMS , unsigned long long (&fprof_acc)[kFuseProfPhases], unsigned long long &fprof_last
+#define PH_FPROF_ARGS , fprof_acc, fprof_last
+#else
+#define PH_FSTAMP(i) \
+    do {             \
+    } while (0)
+#define PH_FPROF_PARAMS
+#define PH_FPROF_ARGS
+#endif
 constexpr unsigned kOut32 = 0x80000000u;  // a buffer offset beyond any num_records: loads 0, stores dropped
 
 struct Args32 {
     int64_t frames;       // frames per Line in this call
     int64_t line_stride;  // elements between Lines
-    int C, N, H;
-    int L;                // valid outputs per tile
+    int C, N, H;          // channels, taps, history frames (N - 1)
+    int HP;               // window frames ahead of a tile's first output: H, or H rounded up to 32
+                          // (fused chain: a tile's first output then opens a 32-position segment)
+    int L;                // valid outputs per tile = 1024 - HP
     int pairs, lines, tiles_per_line;
     int ipl, upl;         // items per Line (tiles x pairs); units (item pairs) per Line
     int64_t nunits;
@@ -28,29 +54,32 @@ struct Args32 {
 };
 
 // ---- the biquad + gain epilogue of the fused chain (chain_fused.hip) ---------------------------
-// Arguments that are the same for every tile of a launch.  Matrices are zero-input state
-// transitions of the S-section DF2T cascade (state order s1_0, s2_0, s1_1, s2_1, ...), computed on
-// the host in long double.
+// Arguments that are the same for every tile of a launch.
 template <int S>
 struct FuseConst {
-    double c[S][5];              // {b0, b1, b2, a1, a2} per section
-    double gain;
-    double A[5][2 * S][2 * S];   // M^(32 * 2^i), i = 0..4: the scan over a tile's 32 segments
-    double ML[2 * S][2 * S];     // M^L: one whole tile
-    double T32[2 * S][2 * S];    // (M^L)^32: one look-back window
-    int has_gain;
-    int D;                       // (M^L)^j is below 2^-90 from j = D on (2^30: never within a window)
+    double c[S][5];  // {b0, b1, b2, a1, a2} per section
+    double gain;     // 1.0 when the chain has no gain stage (x * 1.0 is x, bit for bit)
+    int D;           // (M^L)^j is below 2^-60 from j = D on (2^30: never within a look-back window)
 };
+// Zero-input state transitions of the S-section DF2T cascade (state order s1_0, s2_0, s1_1, s2_1,
+// ...; M = one frame), computed on the host in long double; 2S x 2S matrices, row-major, in ONE
+// device array at these matrix offsets:
+constexpr int kMatAk = 0;    // [17]  (M^32)^j, j = 0..16 : the scan over a tile's 32 segments
+constexpr int kMatML = 17;   //       M^L                 : one whole tile
+constexpr int kMatT32 = 18;  //       (M^L)^32            : one look-back window
+constexpr int kMatTj = 19;   // [33]  (M^L)^j, j = 0..32  : a predecessor at distance j
+constexpr int kMatPk = 52;   // [32]  M^(32 (k - k0)) for k >= k0, else 1: a segment's offset in the tile
+constexpr int kMatCount = 84;
 struct FuseArgs {
-    int k0, n00;                 // H / 32, H % 32: lane and step of a tile's first output
+    int k0;                      // HP / 32: the lane (segment) of a tile's first output; HP % 32 == 0
     unsigned epoch;              // tag of this launch's records (never 0)
     unsigned long long *rec;     // [series][tile][A | P][2 NV] 8-byte {tag, half a double} granules
     const double *state;         // [lines][C][S][2]: the biquad stage's own state, read at a Line's first tile
-    double *state_out;           // same shape: the state after the call, written at a Line's last tile
-                                 // (a second array: Lines of a few tiles have both in flight at once)
-    const double *Tj;            // [33][2S][2S]: (M^L)^j
-    const double *Pk;            // [32][2S][2S]: M^(32 k - H) for k > k0
+    double *seg_state;           // [series][2 channels][2S]: start state of the segment that holds the
+                                 // Line's last frame (for chain_tail_kernel)
+    const double *mats;          // the matrices above
     int *err;                    // set when a bounded spin gives up
+    unsigned long long *prof;    // PH_FUSE_PROF builds: [waves][kFuseProfPhases]
 };
 
 template <int S>
@@ -68,7 +97,7 @@ __device__ __forceinline__ double biquad_step(double x, double (&st)[2 * S], con
     return x;
 }
 
-// out = z + m * v  (2S x 2S, m wave-uniform)
+// out = z + m * v  (2S x 2S)
 template <int S>
 __device__ __forceinline__ void affine(double (&out)[2 * S], const double (&z)[2 * S], const double (&m)[2 * S][2 * S],
                                        const double (&v)[2 * S])
@@ -81,6 +110,28 @@ __device__ __forceinline__ void affine(double (&out)[2 * S], const double (&z)[2
             acc = __builtin_fma(m[i][j], v[j], acc);
         out[i] = acc;
     }
+}
+template <int S>
+__device__ __forceinline__ void load_mat(double (&m)[2 * S][2 * S], const double *__restrict__ mats, int index)
+{
+    const double *src = mats + (size_t)index * (2 * S) * (2 * S);
+#pragma unroll
+    for (int i = 0; i < 2 * S; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * S; ++j)
+            m[i][j] = src[i * 2 * S + j];
+}
+
+// cross-lane moves of a double inside 16-lane rows, on the VALU (no LDS round trip):
+// CTRL 0x110 + d: row_shr:d (lanes whose source falls outside the row get 0);
+// CTRL 0x142 with ROWS 0xA: lane 15 of rows 0 / 2 to every lane of rows 1 / 3 (the others get 0)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROWS, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROWS, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p)
@@ -95,7 +146,7 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned ta
 // One tile (FIR output in lo/hi, natural layout, re/im = the pair's two channels) through the
 // cascade, in place.  Per half-wave = per item:
 //   1. transpose to SEGMENT layout through the item's plane: lane k owns window positions
-//      [32 k, 32 k + 32) (positions below H -- no output -- are written as zeros);
+//      [32 k, 32 k + 32); positions below HP = 32 k0 -- no output -- become zeros;
 //   2. every lane runs its segment from a ZERO state (the exact recurrence) and keeps the end state;
 //   3. a scan over the 32 lanes (s_{k+1} = z_k + M^32 s_k) gives every segment's start state for
 //      a tile that starts from zero, and the tile's own map (M^L, Z);
@@ -106,10 +157,10 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned ta
 //      from its true start state, applies the gain, and the tile goes back to natural layout.
 // Float64 values differ from the ordered recurrence only through the start states (O(1e-16)
 // relative, reassociation of steps 3-4), exactly like the time-segmented biquad.
-template <int S>
+template <int S, bool GENERAL>
 __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb, const Args32 &a,
                                                const FuseArgs &fa, const FuseConst<S> &fc, int line, int tile, int pair,
-                                               bool valid, int l5, int half)
+                                               bool valid, int l5, int half PH_FPROF_PARAMS)
 {
     constexpr int N2 = 2 * S;
     constexpr int NV = 2 * N2;  // doubles per record: two channels x 2S states
@@ -117,6 +168,22 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     const int len = (int)(len64 < a.L ? len64 : a.L);  // output frames of this tile (<= 0: none)
     const bool last_tile = tile == a.tiles_per_line - 1;
     valid = valid && len > 0;
+    const int64_t series = (int64_t)line * a.pairs + pair;
+    unsigned long long *recs = fa.rec + (series * a.tiles_per_line) * (2 * 2 * NV);  // this series' records
+
+    // requested now, wanted later: the first scan matrix; for the forgetful form also this lane's
+    // power of M^L and -- if this lane stands for "tile -1" -- the stage's own state
+    double m0[N2][N2];
+    load_mat<S>(m0, fa.mats, kMatAk + 1);
+    double tj0[N2][N2], own[NV];
+    if constexpr (!GENERAL) {
+        load_mat<S>(tj0, fa.mats, kMatTj + l5);
+        const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
+        const bool mine = valid && tile - 1 - l5 == -1 && l5 < fc.D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            own[j] = mine ? sp[j] : 0.0;
+    }
 
     // ---- 1. segment layout, 2. zero-state pass ----------------------------------------------
     // Channel 0's segment stays in registers; channel 1's stays in the plane (it is the last one
@@ -127,70 +194,81 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     for (int i = 0; i < N2; ++i)
         zr[i] = zi[i] = 0.0;
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
+    for (int r = 0; r < 32; ++r)
+        PH_COL(r) = PH_NAT(r).re;
+    wave_fence();
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            double v = part == 0 ? PH_NAT(r).re : PH_NAT(r).im;
-            if (r < fa.k0)
-                v = 0.0;
-            else if (r == fa.k0)
-                v = l5 >= fa.n00 ? v : 0.0;
-            PH_COL(r) = v;
-        }
-        wave_fence();
-        if (part == 0) {
+    for (int c = 0; c < 32; ++c)
+        xr[c] = PH_ROW(c);
+    wave_fence();
 #pragma unroll
-            for (int c = 0; c < 32; ++c)
-                xr[c] = PH_ROW(c);
-            wave_fence();
+    for (int r = 0; r < 32; ++r)
+        PH_COL(r) = PH_NAT(r).im;
+    wave_fence();
+    {
+        double xz[32];
 #pragma unroll
-            for (int c = 0; c < 32; ++c)
-                (void)biquad_step<S>(xr[c], zr, fc);
-        } else {
-            double xi[32];
+        for (int c = 0; c < 32; ++c)
+            xz[c] = PH_ROW(c);
+        // the two channels' chains interleaved: each step is two dependent fma per section
 #pragma unroll
-            for (int c = 0; c < 32; ++c)
-                xi[c] = PH_ROW(c);
-#pragma unroll
-            for (int c = 0; c < 32; ++c)
-                (void)biquad_step<S>(xi[c], zi, fc);
+        for (int c = 0; c < 32; ++c) {
+            (void)biquad_step<S>(xr[c], zr, fc);
+            (void)biquad_step<S>(xz[c], zi, fc);
         }
     }
-
-    // ---- 3. scan over the half-wave's 32 segments ------------------------------------------------
+    // positions below HP = 32 k0 carry no output (the transform's circular wrap): the lanes that
+    // own them contribute nothing to the scan, and what they compute later is never stored
+    if (l5 < fa.k0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int d = 1 << i;
-        double tr[N2], ti[N2];
+        for (int i = 0; i < N2; ++i)
+            zr[i] = zi[i] = 0.0;
+    }
+    PH_FSTAMP(1);  // to segments + zero-state pass
+
+    // ---- 3. scan over the half-wave's 32 segments: inside 16-lane rows on the VALU, then row 0's
+    //         total into row 1.  Each step's matrix is requested a step ahead (the first one before
+    //         the zero-state pass): one memory round trip per step would cost more than the scan.
+    {
+        double mn[N2][N2], tr[N2], ti[N2];
+#define PH_SCAN_STEP(D_, NEXT_)                                  \
+    load_mat<S>(mn, fa.mats, (NEXT_));                           \
+    _Pragma("unroll") for (int j = 0; j < N2; ++j)               \
+    {                                                            \
+        tr[j] = dpp_f64<0x110 + (D_), 0xF>(zr[j]);               \
+        ti[j] = dpp_f64<0x110 + (D_), 0xF>(zi[j]);               \
+    }                                                            \
+    affine<S>(zr, zr, m0, tr);                                   \
+    affine<S>(zi, zi, m0, ti);                                   \
+    _Pragma("unroll") for (int i = 0; i < N2; ++i)               \
+        _Pragma("unroll") for (int j = 0; j < N2; ++j) m0[i][j] = mn[i][j];
+        PH_SCAN_STEP(1, kMatAk + 2)
+        PH_SCAN_STEP(2, kMatAk + 4)
+        PH_SCAN_STEP(4, kMatAk + 8)
+        PH_SCAN_STEP(8, kMatAk + (l5 & 15) + 1)  // next: lanes 16..31 need (M^32)^(l5 - 15)
+#undef PH_SCAN_STEP
 #pragma unroll
         for (int j = 0; j < N2; ++j) {
-            tr[j] = __shfl_up(zr[j], d, 32);
-            ti[j] = __shfl_up(zi[j], d, 32);
-            if (l5 < d) {
-                tr[j] = 0.0;
-                ti[j] = 0.0;
-            }
+            tr[j] = dpp_f64<0x142, 0xA>(zr[j]);
+            ti[j] = dpp_f64<0x142, 0xA>(zi[j]);
         }
-        affine<S>(zr, zr, fc.A[i], tr);
-        affine<S>(zi, zi, fc.A[i], ti);
+        affine<S>(zr, zr, m0, tr);
+        affine<S>(zi, zi, m0, ti);
     }
     // zr / zi: end state of segment l5 for a zero tile start.  Exclusive form and the tile's aggregate:
     double er[N2], ei[N2], Zr[N2], Zi[N2];
 #pragma unroll
     for (int j = 0; j < N2; ++j) {
-        er[j] = __shfl_up(zr[j], 1, 32);
-        ei[j] = __shfl_up(zi[j], 1, 32);
-        if (l5 == 0) {
-            er[j] = 0.0;
-            ei[j] = 0.0;
-        }
+        const double sr1 = dpp_f64<0x111, 0xF>(zr[j]), si1 = dpp_f64<0x111, 0xF>(zi[j]);
+        const double br = dpp_f64<0x142, 0xA>(zr[j]), bi = dpp_f64<0x142, 0xA>(zi[j]);
+        er[j] = l5 == 16 ? br : sr1;
+        ei[j] = l5 == 16 ? bi : si1;
         Zr[j] = __shfl(zr[j], 31, 32);
         Zi[j] = __shfl(zi[j], 31, 32);
     }
+    PH_FSTAMP(2);  // scan
 
     // ---- 4. the tile's true start state ---------------------------------------------------------
-    const int64_t series = (int64_t)line * a.pairs + pair;
-    unsigned long long *recs = fa.rec + (series * a.tiles_per_line) * (2 * 2 * NV);  // this series' records
     auto publish = [&](int kind, const double (&vr)[N2], const double (&vi)[N2]) {
         if (l5 == 31 && valid && !last_tile) {
             unsigned long long *dst = recs + ((int64_t)tile * 2 + kind) * (2 * NV);
@@ -206,248 +284,257 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         }
     };
     publish(0, Zr, Zi);  // A: the aggregate, before anything is waited for
+    PH_FSTAMP(3);  // publish A
 
     double sr[N2], si[N2];  // start state of the tile
 #pragma unroll
     for (int j = 0; j < N2; ++j)
         sr[j] = si[j] = 0.0;
-    {
-        // R = (M^L)^(32 w) after w whole windows
-        double R[N2][N2];
-#pragma unroll
-        for (int i = 0; i < N2; ++i)
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                R[i][j] = i == j ? 1.0 : 0.0;
-        int base = tile - 1;     // newest predecessor of the current window
-        int dist0 = 0;           // its distance from the tile, in tiles, minus one
-        bool done = !valid;
-        unsigned spins = 0;
-        while (!__all(done)) {
-            const int u = base - l5;   // the predecessor this lane looks at (-1: the stage's own state)
-            int st = 2;                // 2: a P (or nothing to add), 1: an A, 0: not there yet
-            if (!done && u >= 0 && dist0 + l5 < fc.D) {
-                const unsigned long long *r = recs + (int64_t)u * (2 * 2 * NV);
-                const unsigned tp = (unsigned)(granule_load(r + 2 * NV) >> 32);
-                const unsigned ta = (unsigned)(granule_load(r) >> 32);
-                st = tp == fa.epoch ? 2 : (ta == fa.epoch ? 1 : 0);
-            }
-            const unsigned long long bp = __ballot(st == 2), b0 = __ballot(st == 0);
-            const unsigned mp = (unsigned)(bp >> (32 * half)), m0 = (unsigned)(b0 >> (32 * half));
-            const int jp = mp ? __builtin_ctz(mp) : 32, j0 = m0 ? __builtin_ctz(m0) : 32;
-            const bool resolved = jp < j0;            // everything nearer than the first P is an A
-            const bool whole = jp == 32 && j0 == 32;  // 32 A's: take them all and look further back
-            if (!done && (resolved || whole)) {
-                const int jlim = resolved ? jp : 31;
-                double vr[N2], vi[N2];
-#pragma unroll
-                for (int j = 0; j < N2; ++j)
-                    vr[j] = vi[j] = 0.0;
-                if (l5 <= jlim && (st == 1 || (st == 2 && l5 == jp))) {
-                    if (u == -1) {
-                        // the series starts here: the biquad stage's own state (from the last call)
-                        const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
-#pragma unroll
-                        for (int j = 0; j < N2; ++j) {
-                            vr[j] = sp[j];
-                            vi[j] = sp[N2 + j];
-                        }
-                    } else if (u >= 0 && dist0 + l5 < fc.D) {
-                        const unsigned long long *r = recs + ((int64_t)u * 2 + (st == 2 ? 1 : 0)) * (2 * NV);
-                        double pay[NV];
-                        for (unsigned tries = 0;; ++tries) {
-                            bool ok = true;
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) {
-                                const unsigned long long g0 = granule_load(r + 2 * j), g1 = granule_load(r + 2 * j + 1);
-                                ok = ok && (unsigned)(g0 >> 32) == fa.epoch && (unsigned)(g1 >> 32) == fa.epoch;
-                                pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
-                            }
-                            if (ok)
-                                break;
-                            if (tries > (1u << 20)) {
-                                *fa.err = 2;
-                                break;
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < N2; ++j) {
-                            vr[j] = pay[j];
-                            vi[j] = pay[N2 + j];
-                        }
-                    }
-                    // (M^L)^l5 applied to this predecessor's contribution
-                    const double *tj = fa.Tj + (size_t)l5 * N2 * N2;
-                    double m[N2][N2];
-#pragma unroll
-                    for (int i = 0; i < N2; ++i)
-#pragma unroll
-                        for (int j = 0; j < N2; ++j)
-                            m[i][j] = tj[i * N2 + j];
-                    double zero[N2];
-#pragma unroll
-                    for (int j = 0; j < N2; ++j)
-                        zero[j] = 0.0;
-                    double wr[N2], wi[N2];
-                    affine<S>(wr, zero, m, vr);
-                    affine<S>(wi, zero, m, vi);
-#pragma unroll
-                    for (int j = 0; j < N2; ++j) {
-                        vr[j] = wr[j];
-                        vi[j] = wi[j];
-                    }
-                }
-                // sum over the half-wave's lanes, then through the windows already passed
-#pragma unroll
-                for (int sh = 1; sh < 32; sh <<= 1) {
-#pragma unroll
-                    for (int j = 0; j < N2; ++j) {
-                        vr[j] += __shfl_xor(vr[j], sh, 32);
-                        vi[j] += __shfl_xor(vi[j], sh, 32);
-                    }
-                }
-                affine<S>(sr, sr, R, vr);
-                affine<S>(si, si, R, vi);
-                if (resolved) {
-                    done = true;
-                } else {
-                    double Rn[N2][N2];
-#pragma unroll
-                    for (int i = 0; i < N2; ++i)
-#pragma unroll
-                        for (int j = 0; j < N2; ++j) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int k = 0; k < N2; ++k)
-                                acc = __builtin_fma(R[i][k], fc.T32[k][j], acc);
-                            Rn[i][j] = acc;
-                        }
-#pragma unroll
-                    for (int i = 0; i < N2; ++i)
-#pragma unroll
-                        for (int j = 0; j < N2; ++j)
-                            R[i][j] = Rn[i][j];
-                    base -= 32;
-                    dist0 += 32;
-                }
-            } else if (!done) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
-                    *fa.err = 1;
-                    done = true;
-                }
-            }
-        }
-    }
-    {   // P: the tile's true end state, for the tiles after it
-        double pr[N2], pi[N2];
-        affine<S>(pr, Zr, fc.ML, sr);
-        affine<S>(pi, Zi, fc.ML, si);
-        publish(1, pr, pi);
-    }
-
-    // ---- 5. the ordered recurrence from the true start states ------------------------------------
-    double pk[N2][N2];  // per-lane table entry M^(32 l5 - H)
-    {
-        const double *src = fa.Pk + (size_t)l5 * N2 * N2;
-#pragma unroll
-        for (int i = 0; i < N2; ++i)
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                pk[i][j] = src[i * N2 + j];
-    }
-    double str[N2], sti[N2];
-    affine<S>(str, er, pk, sr);
-    affine<S>(sti, ei, pk, si);
-    if (l5 <= fa.k0) {  // lanes before the first output hold zeros; lane k0 gets the tile's start
-                        // state injected at its first output (step n00), exactly
+    if constexpr (!GENERAL) {
+        // The filter forgets within one look-back window ((M^L)^j below 2^-60 from j = D <= 32 on):
+        // the start state is the sum of the D nearest predecessors' zero-start aggregates,
+        //     s = sum_{j < D} (M^L)^j A_{t-1-j}      (the stage's own state stands in for tile -1),
+        // in this fixed order -- no P records, no dependence on how far other tiles have come.
+        const int u = tile - 1 - l5;  // lane j looks at predecessor t - 1 - j
+        const bool need = valid && l5 < fc.D && u >= -1;
+        double wr[N2], wi[N2];
 #pragma unroll
         for (int j = 0; j < N2; ++j)
-            str[j] = sti[j] = 0.0;
+            wr[j] = wi[j] = 0.0;
+        if (need && u == -1) {
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                wr[j] = own[j];
+                wi[j] = own[N2 + j];
+            }
+        }
+        bool ready = !(need && u >= 0);
+        unsigned spins = 0;
+        while (!__all(ready)) {
+            if (!ready) {
+                const unsigned long long *r = recs + (int64_t)u * (2 * 2 * NV);
+                double pay[NV];
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const unsigned long long g0 = granule_load(r + 2 * j), g1 = granule_load(r + 2 * j + 1);
+                    ok = ok && (unsigned)(g0 >> 32) == fa.epoch && (unsigned)(g1 >> 32) == fa.epoch;
+                    pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
+                }
+                if (ok) {
+#pragma unroll
+                    for (int j = 0; j < N2; ++j) {
+                        wr[j] = pay[j];
+                        wi[j] = pay[N2 + j];
+                    }
+                    ready = true;
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                        *fa.err = 1;
+                        ready = true;
+                    }
+                }
+            }
+        }
+        double zero[N2], vr[N2], vi[N2];
+#pragma unroll
+        for (int j = 0; j < N2; ++j)
+            zero[j] = 0.0;
+        affine<S>(vr, zero, tj0, wr);
+        affine<S>(vi, zero, tj0, wi);
+        const int nd = fc.D < 32 ? fc.D : 32;
+        for (int d = 0; d < nd; ++d) {  // uniform trip count, usually 1..3
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                sr[j] += __shfl(vr[j], d, 32);
+                si[j] += __shfl(vi[j], d, 32);
+            }
+        }
+    } else {
+        {
+            // R = (M^L)^(32 w) after w whole windows
+            double R[N2][N2];
+    #pragma unroll
+            for (int i = 0; i < N2; ++i)
+    #pragma unroll
+                for (int j = 0; j < N2; ++j)
+                    R[i][j] = i == j ? 1.0 : 0.0;
+            int base = tile - 1;  // newest predecessor of the current window
+            int dist0 = 0;        // how many predecessors lie between it and the tile
+            bool done = !valid;
+            unsigned spins = 0;
+            while (!__all(done)) {
+                const int u = base - l5;  // the predecessor this lane looks at (-1: the stage's own state)
+                // one round trip: both records of the predecessor, tags and payloads (the lanes past
+                // the filter's memory, past the start of the series, or of a finished half ask nothing)
+                const bool ask = !done && u >= 0 && dist0 + l5 < fc.D;
+                double pa_[NV], pp_[NV];
+                bool oka = true, okp = true;
+                if (ask) {
+                    const unsigned long long *r = recs + (int64_t)u * (2 * 2 * NV);
+    #pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        const unsigned long long a0 = granule_load(r + 2 * j), a1 = granule_load(r + 2 * j + 1);
+                        const unsigned long long p0 = granule_load(r + 2 * NV + 2 * j),
+                                                 p1 = granule_load(r + 2 * NV + 2 * j + 1);
+                        oka = oka && (unsigned)(a0 >> 32) == fa.epoch && (unsigned)(a1 >> 32) == fa.epoch;
+                        okp = okp && (unsigned)(p0 >> 32) == fa.epoch && (unsigned)(p1 >> 32) == fa.epoch;
+                        pa_[j] = __builtin_bit_cast(double, (a1 << 32) | (a0 & 0xFFFFFFFFull));
+                        pp_[j] = __builtin_bit_cast(double, (p1 << 32) | (p0 & 0xFFFFFFFFull));
+                    }
+                }
+                // 2: a P (or nothing to add), 1: an A, 0: not there yet
+                const int st = !ask ? 2 : (okp ? 2 : (oka ? 1 : 0));
+                const unsigned long long bp = __ballot(st == 2), b0 = __ballot(st == 0);
+                const unsigned mp = (unsigned)(bp >> (32 * half)), m0 = (unsigned)(b0 >> (32 * half));
+                const int jp = mp ? __builtin_ctz(mp) : 32, j0 = m0 ? __builtin_ctz(m0) : 32;
+                const bool resolved = jp < j0;            // everything nearer than the first P is an A
+                const bool whole = jp == 32 && j0 == 32;  // 32 A's: take them all and look further back
+                if (!done && (resolved || whole)) {
+                    const int jlim = resolved ? jp : 31;
+                    double vr[N2], vi[N2];
+    #pragma unroll
+                    for (int j = 0; j < N2; ++j)
+                        vr[j] = vi[j] = 0.0;
+                    if (l5 <= jlim && (st == 1 || l5 == jp) && (ask || u == -1)) {
+                        double wr[N2], wi[N2];
+                        if (u == -1) {  // the series starts here: the biquad stage's own state
+                            const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
+    #pragma unroll
+                            for (int j = 0; j < N2; ++j) {
+                                wr[j] = sp[j];
+                                wi[j] = sp[N2 + j];
+                            }
+                        } else {
+    #pragma unroll
+                            for (int j = 0; j < N2; ++j) {
+                                wr[j] = st == 2 ? pp_[j] : pa_[j];
+                                wi[j] = st == 2 ? pp_[N2 + j] : pa_[N2 + j];
+                            }
+                        }
+                        double tj[N2][N2];
+                        load_mat<S>(tj, fa.mats, kMatTj + l5);
+                        double zero[N2];
+    #pragma unroll
+                        for (int j = 0; j < N2; ++j)
+                            zero[j] = 0.0;
+                        affine<S>(vr, zero, tj, wr);  // (M^L)^l5 applied to this predecessor's contribution
+                        affine<S>(vi, zero, tj, wi);
+                    }
+                    // sum over the half-wave's lanes, then through the windows already passed
+    #pragma unroll
+                    for (int sh = 1; sh < 32; sh <<= 1) {
+    #pragma unroll
+                        for (int j = 0; j < N2; ++j) {
+                            vr[j] += __shfl_xor(vr[j], sh, 32);
+                            vi[j] += __shfl_xor(vi[j], sh, 32);
+                        }
+                    }
+                    affine<S>(sr, sr, R, vr);
+                    affine<S>(si, si, R, vi);
+                    if (resolved) {
+                        done = true;
+                    } else {
+                        double t32[N2][N2], Rn[N2][N2];
+                        load_mat<S>(t32, fa.mats, kMatT32);
+    #pragma unroll
+                        for (int i = 0; i < N2; ++i)
+    #pragma unroll
+                            for (int j = 0; j < N2; ++j) {
+                                double acc = 0.0;
+    #pragma unroll
+                                for (int k = 0; k < N2; ++k)
+                                    acc = __builtin_fma(R[i][k], t32[k][j], acc);
+                                Rn[i][j] = acc;
+                            }
+    #pragma unroll
+                        for (int i = 0; i < N2; ++i)
+    #pragma unroll
+                            for (int j = 0; j < N2; ++j)
+                                R[i][j] = Rn[i][j];
+                        base -= 32;
+                        dist0 += 32;
+                    }
+                } else if (!done) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                        *fa.err = 1;
+                        done = true;
+                    }
+                }
+            }
+        }
     }
-    // the Line's last tile leaves the state after its last frame in the biquad stage's own array
-    const int plast = a.H + len - 1;
-    const bool capture = valid && last_tile;
-    const int kl = plast >> 5, jl = plast & 31;
-    double cr[N2], ci[N2];
-#pragma unroll
-    for (int j = 0; j < N2; ++j)
-        cr[j] = ci[j] = 0.0;
-    const bool any_capture = __any(capture);
-    // channel 0 out of registers, channel 1 out of the plane; each result goes back where its
-    // input was
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        if (c == fa.n00 && l5 == fa.k0) {
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                str[j] = sr[j];
-        }
-        double yr = biquad_step<S>(xr[c], str, fc);
-        if (fc.has_gain)
-            yr = yr * fc.gain;
-        xr[c] = yr;
-        if (any_capture && capture && l5 == kl && c == jl) {
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                cr[j] = str[j];
-        }
+    PH_FSTAMP(4);  // look-back
+    if constexpr (GENERAL) {  // P: the tile's true end state, for the tiles after it
+        double ml[N2][N2], pr[N2], pi[N2];
+        load_mat<S>(ml, fa.mats, kMatML);
+        affine<S>(pr, Zr, ml, sr);
+        affine<S>(pi, Zi, ml, si);
+        publish(1, pr, pi);
     }
-    double xi[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c)
-        xi[c] = PH_ROW(c);
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        if (c == fa.n00 && l5 == fa.k0) {
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                sti[j] = si[j];
-        }
-        double yi = biquad_step<S>(xi[c], sti, fc);
-        if (fc.has_gain)
-            yi = yi * fc.gain;
-        xi[c] = yi;
-        if (any_capture && capture && l5 == kl && c == jl) {
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-                ci[j] = sti[j];
-        }
+    PH_FSTAMP(5);  // publish P
+
+    // ---- 5. the ordered recurrence from the true start states ------------------------------------
+    // (lane k0 opens the tile: e = 0 and its table entry is the identity, so it starts from the
+    // tile's start state; lanes below k0 hold zeros and produce nothing that is kept)
+    double str[N2], sti[N2];
+    {
+        double pk[N2][N2];  // M^(32 (l5 - k0))
+        load_mat<S>(pk, fa.mats, kMatPk + l5);
+        affine<S>(str, er, pk, sr);
+        affine<S>(sti, ei, pk, si);
     }
-    if (capture && l5 == kl) {
-        double *sp = fa.state_out + ((int64_t)line * a.C + 2 * pair) * N2;
+    // The Line's last tile: the state after the Line's LAST frame is the biquad stage's state for
+    // the next call.  That frame sits in the middle of a segment (step jl of lane kl), so this
+    // kernel only hands out the segment's true start state; chain_tail_kernel (chain_fused.hip)
+    // walks the <= 32 frames from there.  No second shape of the loop below, nothing inside it.
+    if (valid && last_tile && l5 == ((a.HP + len - 1) >> 5)) {
+        double *sp = fa.seg_state + series * NV;
 #pragma unroll
         for (int j = 0; j < N2; ++j) {
-            sp[j] = cr[j];
-            sp[N2 + j] = ci[j];
+            sp[j] = str[j];
+            sp[N2 + j] = sti[j];
         }
     }
-
-    // ---- back to natural layout (channel 1 first: the plane is still its) ----------------------
-#pragma unroll
-    for (int part = 1; part >= 0; --part) {
-        if (part == 0)
-            wave_fence();
+    {
+        // channel 0 out of registers, channel 1 out of the plane, the two chains interleaved;
+        // results replace the inputs
+        double xi[32];
 #pragma unroll
         for (int c = 0; c < 32; ++c)
-            PH_ROW(c) = part == 0 ? xr[c] : xi[c];
-        wave_fence();
-        if (part == 0) {
+            xi[c] = PH_ROW(c);
 #pragma unroll
-            for (int r = 0; r < 32; ++r)
-                PH_NAT(r).re = PH_COL(r);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 32; ++r)
-                PH_NAT(r).im = PH_COL(r);
+        for (int c = 0; c < 32; ++c) {
+            xr[c] = biquad_step<S>(xr[c], str, fc) * fc.gain;
+            xi[c] = biquad_step<S>(xi[c], sti, fc) * fc.gain;
         }
+        PH_FSTAMP(6);  // pass 3
+        // ---- back to natural layout (channel 1 first: the plane is still its) ------------------
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            PH_ROW(c) = xi[c];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+            PH_NAT(r).im = PH_COL(r);
+        wave_fence();
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            PH_ROW(c) = xr[c];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+            PH_NAT(r).re = PH_COL(r);
+        wave_fence();
+        PH_FSTAMP(7);  // back to natural
     }
-    wave_fence();
 }
 
 // S = 0: the FIR alone.  S = 1, 2: the FIR's tile goes through an S-section biquad cascade and a
 // gain before it is stored (chain_fused.hip; fa / fc are then the epilogue's arguments).
-template <typename TIn, typename TOut, int S = 0>
+template <typename TIn, typename TOut, int S = 0, bool GENERAL = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
 fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
                  const double2 *__restrict__ tw_g, const double2 *__restrict__ hperm_g, const Args32 a,
@@ -493,6 +580,10 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
     const int64_t last = a.frames - 1;
 
+#ifdef PH_FUSE_PROF
+    unsigned long long fprof_acc[kFuseProfPhases] = {};
+    unsigned long long fprof_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t unit = wave_global; unit < a.nunits; unit += wave_stride) {
         // ---- the unit's two items: item0 = 2 slot (half 0), item0 + 1 (half 1) -----------------
         const int item0 = 2 * slot;
@@ -505,7 +596,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         }
         const bool valid = item0 + half < a.ipl;
         const int c0 = 2 * pair;
-        const int64_t fr00 = (int64_t)tile0 * a.L - a.H;  // first window frame of half 0's item
+        const int64_t fr00 = (int64_t)tile0 * a.L - a.HP;  // first window frame of half 0's item
 
         cd lo[16], hi[16];
         // ---- the window: lane l5, register r -> window index l5 + 32 r ---------------------------
@@ -527,7 +618,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             // a Line's first tile: its head is the history
             const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
             const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
-            const int64_t fr0 = (int64_t)tile * a.L - a.H;
+            const int64_t fr0 = (int64_t)tile * a.L - a.HP;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int64_t g = fr0 + l5 + 32 * r;
@@ -538,7 +629,8 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
                             re = (double)in[g * a.C + c0];
                             im = (double)in[g * a.C + c0 + 1];
                         }
-                    } else {
+                    } else if (g >= -(int64_t)a.H) {  // (frames further back only reach positions
+                                                      //  without output when HP > H)
                         re = hist[(g + a.H) * a.C + c0];
                         im = hist[(g + a.H) * a.C + c0 + 1];
                     }
@@ -556,8 +648,14 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         line += a.d_line;
 
         ols32_transform(lo, hi, pa, pb, twl, hlo, hhi);
-        if constexpr (S > 0)
-            fused_epilogue<S>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half);
+        if constexpr (S > 0) {
+            PH_FSTAMP(0);  // window + FIR transform
+            // The epilogue is chains of dependent fma and round trips, a few instructions each: they
+            // go ahead of the other wave's dense transform on this SIMD, which loses nothing by it.
+            __builtin_amdgcn_s_setprio(3);
+            fused_epilogue<S, GENERAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half PH_FPROF_ARGS);
+            __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- store the valid part: window index i >= H is frame t0 + i - H --------------------
         {
@@ -565,15 +663,28 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             TOut *base = out_base + (int64_t)cur_line * a.line_stride + t00 * a.C;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 base, 0, bytes31((a.frames - t00) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
-            const int o0 = (((tile - tile0) * a.L + l5 - a.H) * a.C + c0) * (int)sizeof(TOut);
-            const int i0 = valid ? l5 - a.H : -2048;  // window index - H of register 0: outputs need >= 0
+            const int o0 = (((tile - tile0) * a.L + l5 - a.HP) * a.C + c0) * (int)sizeof(TOut);
+            const int i0 = valid ? l5 - a.HP : -2048;  // window index - HP of register 0: outputs need >= 0
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int off = o0 + r * (int)out_step;
                 buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
             }
         }
+#ifdef PH_FUSE_PROF
+        if constexpr (S > 0)
+            PH_FSTAMP(9);  // stores
+#endif
     }
+#ifdef PH_FUSE_PROF
+    if constexpr (S > 0) {
+        if (fa.prof && lane == 0) {
+            unsigned long long *dst = fa.prof + ((size_t)blockIdx.x * kWaves32 + wave) * kFuseProfPhases;
+            for (int i = 0; i < kFuseProfPhases; ++i)
+                dst[i] = fprof_acc[i];
+        }
+    }
+#endif
 }
 
 
