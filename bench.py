@@ -1,28 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- Msamples/s through the 256-tap FIR Processor on MI355X.
+"""bench.py -- Msamples/s through the Processor stage on MI355X.
 
-Workload (BASELINE.json configs[1], batched on the time axis so that it can reach
-a roofline at all -- SURVEY.md F8): per rank ONE Line, 2 channels, float32,
-`--buffers` consecutive 4096-frame pipe buffers resident in HBM; one *step* = one
-pass of the FIR Processor over that batch (pipe_hip_process_batch), with filter
-history carried from step to step exactly as if the buffers had been pushed
-through ProcessFunc one by one (tests/test_gpu_parity.py proves that equality).
-
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3}]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: Lines are independent (run.go:112-132), so rank r simply owns Line r --
-weak scaling, no data-path collective; RCCL is used only for the barrier and the
-max-over-ranks of the timed region.
+--config names a BASELINE.json config:
+  1 (default, the config the metric is quoted on): per rank ONE Line, 2 channels, float32,
+    `--buffers` consecutive 4096-frame pipe buffers resident in HBM; one step = one pass of the
+    256-tap FIR Processor over that batch (pipe_hip_process_batch), history carried from step to
+    step exactly as if the buffers had gone through ProcessFunc one by one.  Weak scaling: rank r
+    owns Line r.
+  2: configs[2], 64 Lines x 256 buffers of 4096 x 2, the same FIR; the 64 Lines are dealt to the
+    ranks (Line i on rank i mod N) -- strong scaling.
+  3: configs[3], 512 Lines x 8 channels x one 4096-frame buffer, FIR-256 -> biquad -> gain as one
+    fused kernel; Line i on rank i mod N -- strong scaling (SURVEY.md 8d "C4").
+Lines share no state (run.go:112-132): no data-path collective in any of them; RCCL carries only
+the barrier and the max-over-ranks of the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: "roofline" (algorithmic bytes / kernel time from hipEvents on the launch
-stream) and "cpu_baseline" (the oracle's restatement of the reference loop timed
-on the host cores; kind "port").
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+"roofline" (algorithmic bytes / kernel time from hipEvents attached to the kernel's dispatch),
+"cpu_baseline" (the oracle's restatement of the reference loop on one host core; kind "port")
+and, separately labelled, "cpu_baseline_all_cores" and "cpu_optimized".
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -34,7 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 f64 FMA lanes/clk x 2 flop x 2.4 GHz
-BYTES_PER_SAMPLE = {"f32": 8, "f64": 16}  # in + out, taps/history amortised
+BYTES_PER_SAMPLE = {"f32": 8, "f64": 16}  # in + out once, taps/history amortised
 
 
 def parse():
@@ -42,17 +46,67 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--buffers", type=int, default=131072,
-                    help="consecutive 4096-frame buffers of the Line resident in HBM per step (default: 4.3 GB in, 4.3 GB out)")
+    ap.add_argument("--config", type=int, choices=[1, 2, 3], default=1)
+    ap.add_argument("--buffers", type=int, default=None,
+                    help="consecutive 4096-frame buffers per Line resident in HBM per step "
+                         "(config 1: 131072 = 4.3 GB in, 4.3 GB out; config 2: 256; config 3: 1)")
     ap.add_argument("--frames", type=int, default=4096)
-    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=None)
     ap.add_argument("--taps", type=int, default=256)
-    ap.add_argument("--lines", type=int, default=1, help="Lines per rank")
+    ap.add_argument("--lines", type=int, default=None, help="config 1: Lines per rank; configs 2/3: Lines in total")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config[2]-shape line at N = 1")
     ap.add_argument("--cpu-buffers", type=int, default=4096,
                     help="buffers of the same workload timed on the CPU (bounded sample)")
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: the affinity mask, cut by a cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def csrc_sha16() -> str:
+    """Identity of the kernel sources: a PMC figure is only quoted for the build it was taken on."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "pipe_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel: str, algorithmic_bytes: int):
+    """HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE), which cannot run
+    inside this process: the committed figure, and only if it was taken on THIS kernel of THIS
+    build at THIS size -- otherwise null."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        pmc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for entry in pmc.get("kernels", [pmc]):
+        if (entry.get("bench_kernel") == kernel and entry.get("csrc_sha16") == csrc_sha16()
+                and entry.get("algorithmic_bytes_per_launch") == algorithmic_bytes):
+            return entry.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -64,9 +118,8 @@ def main():
     from pipe_amd import shard, synth
 
     rank, world, local = shard.rank_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     # RCCL only for the barrier and the max-over-ranks: Lines do not communicate.
     # PIPE_BENCH_DIST_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks
@@ -81,98 +134,100 @@ def main():
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    F, C, N, K, L = args.frames, args.channels, args.taps, args.buffers, args.lines
+    F, N = args.frames, args.taps
+    cfg = args.config
+    C = args.channels or (8 if cfg == 3 else 2)
+    K = args.buffers or {1: 131072, 2: 256, 3: 1}[cfg]
+    my_lines, total_lines, scaling = shard.plan_lines(cfg, rank, world, args.lines)
+    L = len(my_lines)
+    assert L >= 1, "more ranks than Lines"
     frames_per_line = F * K
     n_elems = L * frames_per_line * C
 
     taps = synth.fir_lowpass_taps(N, f32_rounded=(args.dtype == "f32"))
-    fir = P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=L, max_batch=K)
-    fir.start()
+    kw = dict(dtype=np_dtype, device=local, lines=L, max_batch=K)
+    fir = P.Fir(taps, F, C, **kw)
+    if cfg == 3:
+        proc = P.Chain([fir, P.Biquad(synth.biquad_rbj_lowpass(), F, C, **kw),
+                        P.Gain(0.7071067811865476, F, C, **kw)])
+    else:
+        proc = fir
+    proc.start()
 
-    # synthetic input, generated on the device; global Line i lives on rank i mod world
-    my_lines = shard.line_indices(rank, world, L * world)
+    # synthetic input, generated on the device
     d_in = torch.empty(n_elems, dtype=t_dtype, device="cuda")
     d_out = torch.empty_like(d_in)
     for l, gl in enumerate(my_lines):
         P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl))
     torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream().cuda_stream
 
-    def barrier():
-        shard.barrier(dist)
+    def timed(p, steps, warmup, d_i, d_o, fpl, barrier=False):
+        """(elapsed s, kernel ms total, launches, kernel name) of `steps` passes after `warmup`."""
+        for _ in range(warmup):
+            p.process_batch(d_i, d_o, fpl, stream=stream)
+        torch.cuda.synchronize()
+        p.set_profiling(True)  # hipEvents attached to the dominant kernel's own dispatch
+        p.kernel_time(reset=True)
+        if barrier:
+            shard.barrier(dist)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.process_batch(d_i, d_o, fpl, stream=stream)
+        torch.cuda.synchronize()
+        if barrier:
+            shard.barrier(dist)
+        el = time.perf_counter() - t0
+        kms, n = p.kernel_time(reset=True)
+        p.set_profiling(False)
+        return el, kms, n, p.kernel_name()
 
     # The same workload pinned to the bit-exact direct form (PIPE_HIP_PARAM_EXACT): reported next
-    # to the headline, never as `value`.  It runs BEFORE the headline's warmup: its ~80 ms of full
-    # load also bring clocks and TLBs to steady state, whatever --warmup the caller chose.
+    # to the headline, never as `value`.  It runs BEFORE the headline's warmup: its full load also
+    # brings clocks and TLBs to steady state, whatever --warmup the caller chose.
     exact_ms = None
-    if args.dtype == "f32":
+    if args.dtype == "f32" and cfg == 1:
         fir.set_exact(True)
-        for _ in range(2):
-            fir.process_batch(d_in, d_out, frames_per_line, stream=stream)
-        torch.cuda.synchronize()
-        fir.set_profiling(True)
-        fir.kernel_time(reset=True)
-        for _ in range(5):
-            fir.process_batch(d_in, d_out, frames_per_line, stream=stream)
-        torch.cuda.synchronize()
-        ems, en = fir.kernel_time(reset=True)
-        fir.set_profiling(False)
+        _, ems, en, _ = timed(fir, 5, 2, d_in, d_out, frames_per_line)
         fir.set_exact(False)
         exact_ms = ems / max(en, 1)
 
-    for _ in range(args.warmup):
-        fir.process_batch(d_in, d_out, frames_per_line, stream=stream)
-    torch.cuda.synchronize()
-
-    fir.set_profiling(True)  # hipEvents around the FIR kernel, on the launch stream
-    fir.kernel_time(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fir.process_batch(d_in, d_out, frames_per_line, stream=stream)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms, launches = fir.kernel_time(reset=True)
-    fir.set_profiling(False)
-    kname = fir.kernel_name()
-
+    elapsed, kernel_ms, launches, kname = timed(proc, args.steps, args.warmup, d_in, d_out, frames_per_line,
+                                                barrier=True)
     elapsed = shard.max_over_ranks(elapsed, dist, device=reduce_device)
+    total_samples_per_step = shard.sum_over_ranks(n_elems, dist, device=reduce_device) if world > 1 else n_elems
 
-    # a cheap self-check that work really happened: DC gain of the filter is 1, so
-    # the output mean tracks the input mean (no oracle here: that is tests/ + smoke())
+    # a cheap self-check that work really happened: DC gain of the filter is 1, so the output mean
+    # tracks the input mean (no oracle here: that is tests/ + smoke())
     chk_in = float(d_in[: 1 << 20].double().mean().item())
     chk_out = float(d_out[N * C: (1 << 20)].double().mean().item())
 
-    samples_per_step_rank = n_elems                 # scalar samples = frames x channels
-    value = shard.aggregate_throughput(samples_per_step_rank, args.steps, world, elapsed)
+    value = total_samples_per_step * args.steps / elapsed / 1e6     # scalar samples = frames x channels
     ms_per_step = elapsed / args.steps * 1e3
     bps = BYTES_PER_SAMPLE[args.dtype]
     avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
-    achieved_gbs = samples_per_step_rank * bps / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-    # real float64 flops the launched kernel form executes per scalar sample:
+    achieved_gbs = n_elems * bps / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    # float64 operations the launched kernel form executes per scalar sample:
     #   direct form      : 2 * taps (ordered fma chain, bit-exact)
-    #   overlap-save FFT : 1056 DP instructions (208 fma) per lane per 1024-point item of
-    #                      (1024 - taps + 1) frames x 2 channels -> ~53 flop/sample at 256 taps
-    is_ols = "ols" in kname
+    #   overlap-save FFT : ~1060 DP instructions (~210 of them fma) per lane per 1024-point item
+    is_fused = "chain_fused" in kname
+    is_ols = "ols" in kname or is_fused
     if is_ols:
-        flop_per_sample = (1056 + 208) * 64 / ((1024 - (N - 1)) * 2.0)
+        flop_per_sample = (1058 + 209) * 64 / ((1025 - N) * 2.0)
     else:
         flop_per_sample = 2.0 * N
-    flops = flop_per_sample * samples_per_step_rank
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
-        try:  # PMC passes cannot run inside this process: the committed figure, if it is of this workload
-            pmc = json.load(open(pmc_path))
-            if pmc.get("algorithmic_bytes_per_launch") == samples_per_step_rank * bps and is_ols:
-                traffic = pmc.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    flops = flop_per_sample * n_elems
+    alg_bytes = n_elems * bps
 
+    workload = {
+        1: f"configs[1]: 1 Line/GPU x {C} ch x {F}-frame buffers x {N}-tap FIR, "
+           f"{K} consecutive buffers resident in HBM per step",
+        2: f"configs[2]: {total_lines} Lines x {C} ch x {K} buffers of {F} frames x {N}-tap FIR, "
+           f"Line i on GPU i mod {world}, one launch per step",
+        3: f"configs[3]: {total_lines} Lines x {C} ch x {F}-frame buffer, {N}-tap FIR -> biquad -> gain "
+           f"(one fused kernel), Line i on GPU i mod {world}",
+    }[cfg]
     result = {
         "metric": "Msamples/sec through 256-tap FIR Processor, 48 kHz 2 ch",
         "value": round(value, 3),
@@ -182,16 +237,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64",  # arithmetic type (all forms compute in float64); buffers are config.io_dtype
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: 1 Line/GPU x {C} ch x {F}-frame buffers x {N}-tap FIR, "
-                        f"{K} consecutive buffers resident in HBM per step",
-            "lines_per_gpu": L, "channels": C, "buffer_frames": F, "buffers_per_step": K,
-            "taps": N, "io_dtype": args.dtype, "parallelism": f"line-shard x{world}",
-            "samples": "scalar (frames x channels)",
+            "workload": workload, "baseline_config": cfg,
+            "lines_total": total_lines, "lines_this_gpu": L, "channels": C, "buffer_frames": F,
+            "buffers_per_step": K, "taps": N, "io_dtype": args.dtype,
+            "parallelism": f"line-shard x{world}", "samples": "scalar (frames x channels)",
         },
         "mframes_per_s": round(value / C, 3),
         "roofline": {
@@ -200,16 +254,19 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-            "traffic": traffic,
+            "traffic": committed_traffic(kname, alg_bytes),
             "kernel": kname,
             "avg_kernel_ms": round(avg_kernel_s * 1e3, 5),
             "launches": launches,
-            "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
-            "algorithm": "overlap-save, 1024-point float64 FFT per wave (<= 1 ulp f32 of the oracle)" if is_ols
-                         else "direct form, ordered float64 fma chain (bit-exact)",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithm": ("FIR -> biquad -> gain fused: overlap-save FFT + segment scan + tile look-back "
+                          "(<= 1 ulp f32 of the oracle chain)") if is_fused else
+                         ("overlap-save, 1024-point float64 FFT per half-wave (<= 1 ulp f32 of the oracle)"
+                          if is_ols else "direct form, ordered float64 fma chain (bit-exact)"),
             "flop_per_sample": round(flop_per_sample, 1),
             # float64 VALU rate of the launched form, so that `frac` (HBM) is not misread: the
-            # direct form is VALU-bound long before HBM
+            # direct form is VALU-bound long before HBM, and the overlap-save form
+            # runs at the chip's power cap (profiles/r02_fir_ols32_phase_profile.txt)
             "valu_f64": {"achieved_tflops": round(flops / avg_kernel_s / 1e12, 3) if avg_kernel_s else 0.0,
                          "peak_tflops": F64_VALU_PEAK_TFLOPS,
                          "frac": round(flops / avg_kernel_s / 1e12 / F64_VALU_PEAK_TFLOPS, 4) if avg_kernel_s else 0.0},
@@ -219,29 +276,67 @@ def main():
     if exact_ms:
         result["bit_exact_form"] = {
             "kernel": "fir_direct_kernel", "avg_kernel_ms": round(exact_ms, 5),
-            "msamples_per_s": round(samples_per_step_rank / (exact_ms * 1e-3) / 1e6, 1),
-            "valu_f64_frac": round(2.0 * N * samples_per_step_rank / (exact_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS, 4),
+            "msamples_per_s": round(n_elems / (exact_ms * 1e-3) / 1e6, 1),
+            "valu_f64_frac": round(2.0 * N * n_elems / (exact_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS, 4),
         }
+
+    # SURVEY.md 8(d) "C3" shape next to the headline (N = 1, config 1 only): 64 Lines x 256 buffers,
+    # after a warm-up long enough to be at steady state (short launches after an idle period read
+    # the clock ramp)
+    if cfg == 1 and world == 1 and not args.no_secondary and args.dtype == "f32":
+        del d_out
+        L2, K2 = 64, 256
+        n2 = L2 * F * K2 * C
+        with P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=L2, max_batch=K2) as f2:
+            f2.start()
+            di = d_in[:n2]
+            do = torch.empty_like(di)
+            _, kms2, nl2, kn2 = timed(f2, 100, 300, di, do, F * K2)
+            ms2 = kms2 / max(nl2, 1)
+            result["c3_shape"] = {
+                "workload": f"SURVEY 8d C3: {L2} Lines x {K2} buffers x {F} x {C} f32 resident, one launch per step",
+                "kernel": kn2, "avg_kernel_ms": round(ms2, 5),
+                "msamples_per_s": round(n2 / (ms2 * 1e-3) / 1e6, 1),
+                "roofline_frac": round(n2 * bps / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "warmup_launches": 300, "timed_launches": 100,
+            }
+            del do
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # cpu_baseline leg: the oracle is the thing timed
-        cb = O.cpu_baseline(lines=1, channels=C, frames=F, buffers=args.cpu_buffers, ntaps=N, threads=1)
+        cb = O.cpu_baseline(lines=1, channels=2, frames=F, buffers=args.cpu_buffers, ntaps=N, threads=1)
         result["cpu_baseline"] = {
             "value": round(cb["msamples_per_s"], 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"1 Line x {C} ch x {F}-frame buffers x {args.cpu_buffers} buffers, {N}-tap FIR, "
+            "sample": f"1 Line x 2 ch x {F}-frame buffers x {args.cpu_buffers} buffers, {N}-tap FIR, "
                       f"oracle restatement of pipe.Run (sync, 1 thread), {cb['seconds']:.1f} s",
         }
-        ncpu = os.cpu_count() or 1
-        per = max(8, args.cpu_buffers // 16)
-        cbm = O.cpu_baseline(lines=ncpu, channels=C, frames=F, buffers=per, ntaps=N, threads=ncpu)
+        ncpu = usable_cores()
+        per = max(8, 2 * args.cpu_buffers // max(ncpu, 1))
+        cbm = O.cpu_baseline(lines=ncpu, channels=2, frames=F, buffers=per, ntaps=N, threads=ncpu)
         result["cpu_baseline_all_cores"] = {
             "value": round(cbm["msamples_per_s"], 4), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
-            "sample": f"{ncpu} Lines (one per thread) x {per} buffers each, {cbm['seconds']:.1f} s",
+            "sample": f"{ncpu} Lines (one thread each; usable cores = affinity mask cut by the cgroup quota) "
+                      f"x {per} buffers each, {cbm['seconds']:.1f} s",
         }
+        try:
+            # ~10^10 scalar samples: a few seconds on a current server CPU
+            cbo = O.cpu_optimized(lines=4 * ncpu, channels=2, frames=F,
+                                  buffers=max(64, int(1.2e10 / (4 * ncpu * F * 2))), ntaps=N, threads=ncpu)
+            result["cpu_optimized"] = {
+                "value": round(cbo["msamples_per_s"], 3), "unit": "Msamples/s", "cores": ncpu,
+                "kind": "optimised float32 CPU FIR (AVX via -O3 -march=native, float32 accumulation): "
+                        "NOT the reference's algorithm, NOT bit-compatible with the oracle; reported "
+                        "separately from cpu_baseline (SURVEY.md 8d)",
+                "sample": f"{4 * ncpu} Lines x {cbo['buffers_per_line']} buffers, {cbo['seconds']:.1f} s",
+            }
+            result["cpu_baseline_all_cores"]["speedup_over_1_core"] = round(
+                cbm["msamples_per_s"] / max(cb["msamples_per_s"], 1e-9), 2)
+        except Exception as e:  # noqa: BLE001 -- an optional leg must not cost the bench line
+            result["cpu_optimized"] = {"error": str(e)[:200]}
 
     if rank == 0:
         print(json.dumps(result))
-    fir.close()
+    proc.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -374,3 +374,19 @@ def cpu_baseline(lines: int, channels: int, frames: int, buffers: int, ntaps: in
     out = subprocess.check_output([os.path.join(_HERE, "cpu_baseline"), str(lines), str(channels),
                                    str(frames), str(buffers), str(ntaps), str(threads)])
     return json.loads(out.decode())
+
+
+def cpu_optimized(lines: int, channels: int, frames: int, buffers: int, ntaps: int, threads: int = 1) -> dict:
+    """Time the OPTIMISED float32 CPU FIR (oracle/cpu_fir_opt.c: not the reference's algorithm,
+    not bit-compatible -- bench.py reports it separately from cpu_baseline).  Compiled with
+    -march=native on the box that runs it (a binary built elsewhere may use instructions this
+    host lacks), into a temporary file."""
+    import json
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "cpu_fir_opt")
+        subprocess.check_call(["gcc", "-O3", "-std=c11", "-march=native", "-ffast-math", "-o", exe,
+                               os.path.join(_HERE, "cpu_fir_opt.c"), "-lm", "-lpthread"])
+        out = subprocess.check_output([exe, str(lines), str(channels), str(frames), str(buffers), str(ntaps),
+                                       str(threads)])
+    return json.loads(out.decode())

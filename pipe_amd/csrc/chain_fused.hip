@@ -127,16 +127,28 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
     if (live) {
         const float *__restrict__ in = in_base + (int64_t)line * a.line_stride + ch;
         const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
-        for (int i = l5; i < wlen; i += 32) {
+        // all loads of a lane first, then the LDS stores: one memory round trip, not one per trip
+        constexpr int kMaxTrips = (32 + 511 + 31) / 32;  // taps <= 512
+        double v[kMaxTrips];
+#pragma unroll
+        for (int t = 0; t < kMaxTrips; ++t) {
+            const int i = l5 + 32 * t;
             const int64_t g = f0 - a.H + i;
-            double v = 0.0;
-            if (g >= 0) {
-                if (g < a.frames)
-                    v = (double)in[g * a.C];
-            } else if (g >= -(int64_t)a.H) {
-                v = hist[(g + a.H) * a.C];
+            v[t] = 0.0;
+            if (i < wlen) {
+                if (g >= 0) {
+                    if (g < a.frames)
+                        v[t] = (double)in[g * a.C];
+                } else if (g >= -(int64_t)a.H) {
+                    v[t] = hist[(g + a.H) * a.C];
+                }
             }
-            xs[i] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < kMaxTrips; ++t) {
+            const int i = l5 + 32 * t;
+            if (i < wlen)
+                xs[i] = v[t];
         }
     }
     __syncthreads();
@@ -145,10 +157,22 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
     // FIR output of frame f0 + l5: acc = fma(h[k], x[f - k], acc), k = 0..N-1
     double y = 0.0;
     {
+        // (four interleaved partial sums: the dependent fma chain would otherwise be 256 deep;
+        // this value only seeds a state, nothing compares it bit for bit)
         const double *w = xs + a.H + l5;
         const tail_const_f64 h = (tail_const_f64)taps;
-        for (int k = 0; k < a.N; ++k)
-            y = __builtin_fma(h[k], w[-k], y);
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 4 <= a.N; k += 4) {
+            y0 = __builtin_fma(h[k], w[-k], y0);
+            y1 = __builtin_fma(h[k + 1], w[-k - 1], y1);
+            y2 = __builtin_fma(h[k + 2], w[-k - 2], y2);
+            y3 = __builtin_fma(h[k + 3], w[-k - 3], y3);
+        }
+        for (; k < a.N; ++k)
+            y0 = __builtin_fma(h[k], w[-k], y0);
+        y = (y0 + y1) + (y2 + y3);
     }
     double st[N2];
     const double *sp = a.seg_state + ((int64_t)(line * (a.C / 2) + ch / 2) * 2 + (ch & 1)) * N2;
@@ -175,7 +199,6 @@ struct Plan::Impl {
     bool has_gain = false;
     double gain = 1.0;
     FuseConst<1> c1{};
-    FuseConst<2> c2{};
     int D = 1 << 30;
     unsigned epoch = 0;
     size_t rec_granules = 0;
@@ -222,13 +245,8 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
             D = j;
     }
     I.D = D;
-    if (S == 1) {
-        std::memcpy(I.c1.c, coeffs, sizeof(double) * 5);
-        I.c1.D = D;
-    } else {
-        std::memcpy(I.c2.c, coeffs, sizeof(double) * 10);
-        I.c2.D = D;
-    }
+    std::memcpy(I.c1.c, coeffs, sizeof(double) * 5 * (S < 1 ? S : 1));
+    I.c1.D = D;
     const size_t bytes = sizeof(double) * ols::kMatCount * kMaxN2 * kMaxN2;
     if (!I.mats.p) {
         PH_TRY(I.mats.alloc(bytes));
@@ -253,6 +271,13 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     const int k0 = H / 32;
     for (int k = 0; k < 32; ++k)
         store_flat(h + (ols::kMatPk + k) * mm, k > k0 ? power(M, 32L * (k - k0)) : identity(n));
+    {
+        Mat w = identity(n);
+        for (int k = 0; k <= 32; ++k) {
+            store_flat(h + (ols::kMatWw + k) * mm, w);
+            w = mul(w, T[32]);
+        }
+    }
     PH_HIP(hipMemcpyAsync(I.mats.p, h, sizeof(double) * ols::kMatCount * mm, hipMemcpyHostToDevice, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);
     I.S = S;
@@ -389,30 +414,19 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
     static const bool force_general = std::getenv("PIPE_HIP_CHAIN_GENERAL") != nullptr;
     const bool general = force_general || I.D > 32;
-    if (S == 1) {
-        I.c1.gain = has_gain ? gain : 1.0;
-        if (general) {
-            I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
-            PH_TRY((launch<1, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
-        } else {
-            I.c1.D = I.D;
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
-            PH_TRY((launch<1, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
-        }
+    if (S != 1)
+        return PIPE_HIP_EINVAL;  // kMaxFusedSections
+    I.c1.gain = has_gain ? gain : 1.0;
+    if (general) {
+        I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
+        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
+        PH_TRY((launch<1, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     } else {
-        I.c2.gain = has_gain ? gain : 1.0;
-        if (general) {
-            I.c2.D = force_general && I.D <= 32 ? I.D : (1 << 30);
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain,general>";
-            PH_TRY((launch<2, true>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
-        } else {
-            I.c2.D = I.D;
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
-            PH_TRY((launch<2, false>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
-        }
+        I.c1.D = I.D;
+        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
+        PH_TRY((launch<1, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     }
-    {   // the state after every Line's last frame
+    if (!std::getenv("PIPE_HIP_CHAIN_NO_TAIL")) {  // (debug switch) the state after every Line's last frame
         TailArgs ta{};
         ta.frames = frames;
         ta.line_stride = a.line_stride;
@@ -427,12 +441,8 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.state = bq.state;
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
-        if (S == 1)
-            hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c1);
-        else
-            hipLaunchKernelGGL(chain_tail_kernel<2>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c2);
+        hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                           static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c1);
         PH_HIP(hipGetLastError());
     }
     return PIPE_HIP_OK;

@@ -8,7 +8,12 @@
 namespace pipehip {
 namespace fused {
 
-constexpr int kMaxFusedSections = 2;
+// One section.  The two-section instantiations of the kernel need more registers than a wave has
+// (VGPR spills), and hipcc places spill stores inside exec-masked regions of this kernel -- lanes
+// that were masked off then reload garbage (seen: wrong channel offsets at the store).  Only
+// spill-free instantiations are launched (scripts/check_spills.sh); longer cascades take the
+// staged chain.
+constexpr int kMaxFusedSections = 1;
 
 class Plan {
 public:

@@ -69,7 +69,9 @@ constexpr int kMatML = 17;   //       M^L                 : one whole tile
 constexpr int kMatT32 = 18;  //       (M^L)^32            : one look-back window
 constexpr int kMatTj = 19;   // [33]  (M^L)^j, j = 0..32  : a predecessor at distance j
 constexpr int kMatPk = 52;   // [32]  M^(32 (k - k0)) for k >= k0, else 1: a segment's offset in the tile
-constexpr int kMatCount = 84;
+constexpr int kMatWw = 84;   // [33]  (M^L)^(32 w), w = 0..32: w whole look-back windows
+constexpr int kMatCount = 117;
+constexpr int kMaxWindows = 32;  // a look-back that needs more (> 1024 tiles to the nearest P) gives up
 struct FuseArgs {
     int k0;                      // HP / 32: the lane (segment) of a tile's first output; HP % 32 == 0
     unsigned epoch;              // tag of this launch's records (never 0)
@@ -353,39 +355,23 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         }
     } else {
         {
-            // R = (M^L)^(32 w) after w whole windows
-            double R[N2][N2];
-    #pragma unroll
-            for (int i = 0; i < N2; ++i)
-    #pragma unroll
-                for (int j = 0; j < N2; ++j)
-                    R[i][j] = i == j ? 1.0 : 0.0;
             int base = tile - 1;  // newest predecessor of the current window
-            int dist0 = 0;        // how many predecessors lie between it and the tile
+            int dist0 = 0;        // how many predecessors lie between it and the tile (32 per window passed)
             bool done = !valid;
             unsigned spins = 0;
             while (!__all(done)) {
                 const int u = base - l5;  // the predecessor this lane looks at (-1: the stage's own state)
-                // one round trip: both records of the predecessor, tags and payloads (the lanes past
-                // the filter's memory, past the start of the series, or of a finished half ask nothing)
+                // tags first (the first granule of each record); the payload of the chosen record is
+                // fetched after the decision: fewer registers in flight than both records whole
                 const bool ask = !done && u >= 0 && dist0 + l5 < fc.D;
-                double pa_[NV], pp_[NV];
-                bool oka = true, okp = true;
+                const unsigned long long *r = recs + (int64_t)(ask ? u : 0) * (2 * 2 * NV);
+                unsigned ta = 0, tp = 0;
                 if (ask) {
-                    const unsigned long long *r = recs + (int64_t)u * (2 * 2 * NV);
-    #pragma unroll
-                    for (int j = 0; j < NV; ++j) {
-                        const unsigned long long a0 = granule_load(r + 2 * j), a1 = granule_load(r + 2 * j + 1);
-                        const unsigned long long p0 = granule_load(r + 2 * NV + 2 * j),
-                                                 p1 = granule_load(r + 2 * NV + 2 * j + 1);
-                        oka = oka && (unsigned)(a0 >> 32) == fa.epoch && (unsigned)(a1 >> 32) == fa.epoch;
-                        okp = okp && (unsigned)(p0 >> 32) == fa.epoch && (unsigned)(p1 >> 32) == fa.epoch;
-                        pa_[j] = __builtin_bit_cast(double, (a1 << 32) | (a0 & 0xFFFFFFFFull));
-                        pp_[j] = __builtin_bit_cast(double, (p1 << 32) | (p0 & 0xFFFFFFFFull));
-                    }
+                    ta = (unsigned)(granule_load(r) >> 32);
+                    tp = (unsigned)(granule_load(r + 2 * NV) >> 32);
                 }
                 // 2: a P (or nothing to add), 1: an A, 0: not there yet
-                const int st = !ask ? 2 : (okp ? 2 : (oka ? 1 : 0));
+                const int st = !ask ? 2 : (tp == fa.epoch ? 2 : (ta == fa.epoch ? 1 : 0));
                 const unsigned long long bp = __ballot(st == 2), b0 = __ballot(st == 0);
                 const unsigned mp = (unsigned)(bp >> (32 * half)), m0 = (unsigned)(b0 >> (32 * half));
                 const int jp = mp ? __builtin_ctz(mp) : 32, j0 = m0 ? __builtin_ctz(m0) : 32;
@@ -407,10 +393,27 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                                 wi[j] = sp[N2 + j];
                             }
                         } else {
+                            const unsigned long long *rr = r + (st == 2 ? 2 * NV : 0);
+                            double pay[NV];
+                            for (unsigned tries = 0;; ++tries) {  // the other granules land with the first
+                                bool ok = true;
+    #pragma unroll
+                                for (int j = 0; j < NV; ++j) {
+                                    const unsigned long long g0 = granule_load(rr + 2 * j), g1 = granule_load(rr + 2 * j + 1);
+                                    ok = ok && (unsigned)(g0 >> 32) == fa.epoch && (unsigned)(g1 >> 32) == fa.epoch;
+                                    pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
+                                }
+                                if (ok)
+                                    break;
+                                if (tries > (1u << 20)) {
+                                    *fa.err = 2;
+                                    break;
+                                }
+                            }
     #pragma unroll
                             for (int j = 0; j < N2; ++j) {
-                                wr[j] = st == 2 ? pp_[j] : pa_[j];
-                                wi[j] = st == 2 ? pp_[N2 + j] : pa_[N2 + j];
+                                wr[j] = pay[j];
+                                wi[j] = pay[N2 + j];
                             }
                         }
                         double tj[N2][N2];
@@ -431,28 +434,18 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                             vi[j] += __shfl_xor(vi[j], sh, 32);
                         }
                     }
-                    affine<S>(sr, sr, R, vr);
-                    affine<S>(si, si, R, vi);
+                    {   // through the windows already passed: (M^L)^(32 w), from the table
+                        double R[N2][N2];
+                        load_mat<S>(R, fa.mats, kMatWw + (dist0 >> 5));
+                        affine<S>(sr, sr, R, vr);
+                        affine<S>(si, si, R, vi);
+                    }
                     if (resolved) {
                         done = true;
+                    } else if ((dist0 >> 5) + 1 > kMaxWindows) {
+                        *fa.err = 3;
+                        done = true;
                     } else {
-                        double t32[N2][N2], Rn[N2][N2];
-                        load_mat<S>(t32, fa.mats, kMatT32);
-    #pragma unroll
-                        for (int i = 0; i < N2; ++i)
-    #pragma unroll
-                            for (int j = 0; j < N2; ++j) {
-                                double acc = 0.0;
-    #pragma unroll
-                                for (int k = 0; k < N2; ++k)
-                                    acc = __builtin_fma(R[i][k], t32[k][j], acc);
-                                Rn[i][j] = acc;
-                            }
-    #pragma unroll
-                        for (int i = 0; i < N2; ++i)
-    #pragma unroll
-                            for (int j = 0; j < N2; ++j)
-                                R[i][j] = Rn[i][j];
                         base -= 32;
                         dist0 += 32;
                     }

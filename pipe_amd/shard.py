@@ -17,6 +17,19 @@ def line_indices(rank: int, world: int, total_lines: int) -> List[int]:
     return list(range(rank, total_lines, world))
 
 
+def plan_lines(config: int, rank: int, world: int, lines: Optional[int] = None):
+    """Which Lines this rank runs for bench.py --config N (BASELINE.json configs[N]).
+    Returns (global Line indices of this rank, Lines in total, "weak" | "strong").
+      config 1: `lines` (default 1) Lines PER rank -- the job grows with the ranks: weak scaling;
+      config 2 / 3: 64 / 512 Lines IN TOTAL (or `lines`), Line i on rank i mod world: strong scaling."""
+    if config == 1:
+        per = lines or 1
+        total = per * world
+        return line_indices(rank, world, total), total, "weak"
+    total = lines or (64 if config == 2 else 512)
+    return line_indices(rank, world, total), total, "strong"
+
+
 def rank_from_env() -> Tuple[int, int, int]:
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
             int(os.environ.get("LOCAL_RANK", "0")))

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KEEP = ("fir_", "ols", "gain_kernel", "biquad_kernel", "resample_kernel", "mix_kernel", "chain")
+KEEP = ("fir_", "ols", "gain_kernel", "biquad", "resample", "mix_kernel", "chain")
 
 print(f"# rocprofv3 summary for {os.path.basename(out.rstrip('/'))}")
 for p in sorted(glob.glob(os.path.join(out, "trace", "**", "*.db"), recursive=True)):

@@ -61,3 +61,16 @@ def test_create_without_gpu_fails_loudly_not_silently(lib):
     with pytest.raises(PipeHipError) as e:
         P.Gain(0.5, 512, 2)
     assert e.value.status == ENODEV  # no CPU fallback exists
+
+
+def test_library_has_no_vgpr_spills():
+    """hipcc (ROCm 7.2) may place a spill store inside an exec-masked region of a kernel; the lanes
+    masked off at the spill then reload garbage (seen on a two-section form of the fused chain
+    kernel: wrong channel offsets at the store).  So no kernel of the library may spill VGPRs:
+    scripts/check_spills.sh recompiles every .hip with -Rpass-analysis=kernel-resource-usage."""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "check_spills.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -85,7 +85,12 @@ def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, cal
     rng = np.random.default_rng(7 + lines * 31 + C)
     x = rng.uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
     got, names = run_chain(taps, q, g, x, calls)
-    assert all("chain_fused_kernel" in n for n in names), names
+    if len(q) == 1:
+        assert all("chain_fused_kernel" in n for n in names), names
+    else:
+        # cascades of two sections take the staged chain (overlap-save FIR, time-segmented biquad):
+        # the fused kernel's two-section form does not fit a wave's registers (chain_fused.hpp)
+        assert all("chain_fused" not in n for n in names), names
     assert not np.isnan(got).any()
     worst, differ = 0.0, 0
     for l in sorted({0, lines // 2, lines - 1}):

@@ -39,6 +39,14 @@ def _worker(rank, world, port, total_lines, out_dir):
     elapsed = time.perf_counter() - t0
     worst = shard.max_over_ranks(elapsed, dist)
     n_lines = shard.sum_over_ranks(float(len(mine)), dist)
+    # bench.py --config 2 / 3: a fixed set of Lines dealt to the ranks (strong scaling); every rank
+    # sums the ranks' sample counts exactly as bench.py does for `value`
+    for cfg, total in ((2, 64), (3, 512)):
+        got, tot, kind = shard.plan_lines(cfg, rank, world)
+        assert tot == total and kind == "strong" and got == list(range(rank, total, world))
+        assert shard.sum_over_ranks(float(len(got)), dist) == total
+    got, tot, kind = shard.plan_lines(1, rank, world, 3)
+    assert kind == "weak" and tot == 3 * world and len(got) == 3
     np.save(os.path.join(out_dir, f"r{rank}.npy"),
             np.array([elapsed, worst, n_lines] + [v for _, v in sorted(sums.items())] ))
     dist.destroy_process_group()
