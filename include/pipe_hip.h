@@ -159,10 +159,13 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,
                          int32_t frames, void *out);
 
-/* Depth-1 asynchronous form of ProcessFunc, mirroring fitting.Async's channel of
- * capacity 1 (internal/fitting/fitting.go:56-60): submit() stages buffer k and
- * returns while the device works; collect() blocks for buffer k.  At most one
- * buffer may be in flight per handle (PIPE_HIP_ESTATE otherwise). */
+/* Asynchronous form of ProcessFunc, mirroring a link of fitting.Async (a channel of capacity 1
+ * plus the message in the receiver's hand, internal/fitting/fitting.go:56-60): submit() stages
+ * buffer k and returns while the device works; collect() blocks for the OLDEST buffer in flight.
+ * Up to TWO buffers may be in flight per handle (two staging slots): submit(k + 1) before
+ * collect(k) overlaps the staging and launch of one buffer with the kernels and transfers of the
+ * other.  A third submit, a collect with nothing in flight, and pipe_hip_process /
+ * pipe_hip_process_lines while something is in flight return PIPE_HIP_ESTATE. */
 int pipe_hip_submit(pipe_hip_processor *p, const void *in, int32_t in_frames);
 int pipe_hip_collect(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames);
 

@@ -130,8 +130,9 @@ pipe_hip_processor::~pipe_hip_processor()
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
     }
-    if (done)
-        (void)hipEventDestroy(done);
+    for (Staging &g : stg)
+        if (g.done)
+            (void)hipEventDestroy(g.done);
 }
 
 int pipe_hip_processor::select_device() const
@@ -146,31 +147,33 @@ int pipe_hip_processor::init_common(const pipe_hip_config *c)
     cfg = *c;
     PH_TRY(select_device());
     PH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    PH_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    for (Staging &g : stg)
+        PH_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     return PIPE_HIP_OK;
 }
 
 // Staging for the host-pointer form: one pipe buffer per Line in, the largest
 // possible output per Line out.  Allocated on first use so that handles driven
 // only through the device-resident batch entry never pay for it.
-int pipe_hip_processor::ensure_staging()
+int pipe_hip_processor::ensure_staging(int slot)
 {
-    if (d_in.p)
+    Staging &g = stg[slot];
+    if (g.d_in.p)
         return PIPE_HIP_OK;
     const size_t es = dtype_size(cfg.dtype);
     // (+16 bytes per Line: the runs of a ragged pipe_hip_process_lines pass start 16-byte aligned)
     const size_t in_b = es * (size_t)cfg.lines * (size_t)cfg.buffer_size * (size_t)cfg.channels + 16u * (size_t)cfg.lines;
     const size_t out_f = (size_t)max_out_frames(cfg.buffer_size);
     const size_t out_b = es * (size_t)cfg.lines * out_f * (size_t)out_channels() + 16u * (size_t)cfg.lines;
-    PH_TRY(d_in.alloc(in_b));
-    PH_TRY(d_out.alloc(out_b));
-    PH_TRY(h_in.alloc(in_b));
-    PH_TRY(h_out.alloc(out_b));
+    PH_TRY(g.d_in.alloc(in_b));
+    PH_TRY(g.d_out.alloc(out_b));
+    PH_TRY(g.h_in.alloc(in_b));
+    PH_TRY(g.h_out.alloc(out_b));
     // device-side aliases of the pinned buffers (zero-copy path of small buffers)
-    if (hipHostGetDevicePointer(&hd_in, h_in.p, 0) != hipSuccess ||
-        hipHostGetDevicePointer(&hd_out, h_out.p, 0) != hipSuccess) {
+    if (hipHostGetDevicePointer(&g.hd_in, g.h_in.p, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&g.hd_out, g.h_out.p, 0) != hipSuccess) {
         (void)hipGetLastError();
-        hd_in = hd_out = nullptr;
+        g.hd_in = g.hd_out = nullptr;
     }
     return PIPE_HIP_OK;
 }
@@ -184,17 +187,20 @@ int finish_create(int rc, pipe_hip_processor **out)
     return rc;
 }
 
-// stage `in` and queue H2D -> stage body -> D2H on the handle's stream
+// stage `in` and queue H2D -> stage body -> D2H on the handle's stream.  Up to two buffers may be
+// in flight: the second one's staging and launch overlap the first one's kernels and transfers.
 int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_t out_cap_hint)
 {
     if (!p->single_input())
         return PIPE_HIP_EINVAL;
     if (in_frames < 0 || in_frames > p->cfg.buffer_size || (!in && in_frames > 0))
         return PIPE_HIP_EINVAL;
-    if (p->in_flight)
+    if (p->in_flight >= 2)
         return PIPE_HIP_ESTATE;
     PH_TRY(p->select_device());
-    PH_TRY(p->ensure_staging());
+    const int slot = p->submit_slot;
+    PH_TRY(p->ensure_staging(slot));
+    pipe_hip_processor::Staging &g = p->stg[slot];
     const size_t es = dtype_size(p->cfg.dtype);
     const size_t in_b = es * (size_t)p->cfg.lines * (size_t)in_frames * (size_t)p->cfg.channels;
     int64_t out_frames = in_frames;
@@ -217,36 +223,37 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
         return e ? (size_t)std::atoll(e) : (size_t)(1u << 20);
     }();
     const size_t out_b_cap = es * (size_t)p->cfg.lines * (size_t)cap * (size_t)p->out_channels();
-    const bool zero_copy = in_b <= zero_copy_max && out_b_cap <= zero_copy_max && p->hd_in && p->hd_out;
+    const bool zero_copy = in_b <= zero_copy_max && out_b_cap <= zero_copy_max && g.hd_in && g.hd_out;
     if (in_b)
-        std::memcpy(p->h_in.p, in, in_b);
+        std::memcpy(g.h_in.p, in, in_b);
     if (zero_copy) {
-        PH_TRY(p->run_var(p->hd_in, p->cfg.dtype, in_frames, p->hd_out, p->cfg.dtype, cap, &out_frames,
-                          p->stream));
+        PH_TRY(p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, cap, &out_frames, p->stream));
     } else {
         if (in_b)
-            PH_HIP(hipMemcpyAsync(p->d_in.p, p->h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
-        PH_TRY(p->run_var(p->d_in.p, p->cfg.dtype, in_frames, p->d_out.p, p->cfg.dtype, cap, &out_frames,
-                          p->stream));
+            PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
+        PH_TRY(p->run_var(g.d_in.p, p->cfg.dtype, in_frames, g.d_out.p, p->cfg.dtype, cap, &out_frames, p->stream));
         const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
                              (size_t)p->out_channels();
         if (out_b)
-            PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
+            PH_HIP(hipMemcpyAsync(g.h_out.p, g.d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
     }
-    PH_HIP(hipEventRecord(p->done, p->stream));
-    p->in_flight = true;
-    p->in_flight_out_frames = (int32_t)out_frames;
+    PH_HIP(hipEventRecord(g.done, p->stream));
+    g.out_frames = (int32_t)out_frames;
+    p->submit_slot ^= 1;
+    p->in_flight += 1;
     return PIPE_HIP_OK;
 }
 
+// the OLDEST buffer in flight
 int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32_t *out_frames)
 {
-    if (!p->in_flight)
+    if (p->in_flight < 1)
         return PIPE_HIP_ESTATE;
     PH_TRY(p->select_device());
-    PH_HIP(hipEventSynchronize(p->done));
-    p->in_flight = false;
-    const int32_t n = p->in_flight_out_frames;
+    pipe_hip_processor::Staging &g = p->stg[(p->submit_slot - p->in_flight) & 1];
+    PH_HIP(hipEventSynchronize(g.done));
+    p->in_flight -= 1;
+    const int32_t n = g.out_frames;
     if (n > out_cap_frames)
         return PIPE_HIP_ECAP;
     const size_t es = dtype_size(p->cfg.dtype);
@@ -255,14 +262,14 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
         return PIPE_HIP_EINVAL;
     if (p->fixed_rate() || p->cfg.lines == 1) {
         if (row)
-            std::memcpy(out, p->h_out.p, row * (size_t)p->cfg.lines);
+            std::memcpy(out, g.h_out.p, row * (size_t)p->cfg.lines);
     } else {
         // rate changer with several Lines: device rows are `cap` frames apart,
         // the caller's are out_cap_frames apart
         const size_t src_stride = es * (size_t)p->max_out_frames(p->cfg.buffer_size) * (size_t)p->out_channels();
         const size_t dst_stride = es * (size_t)out_cap_frames * (size_t)p->out_channels();
         for (int l = 0; l < p->cfg.lines; ++l)
-            std::memcpy((char *)out + dst_stride * l, (const char *)p->h_out.p + src_stride * l, row);
+            std::memcpy((char *)out + dst_stride * l, (const char *)g.h_out.p + src_stride * l, row);
     }
     if (out_frames)
         *out_frames = n;
@@ -373,8 +380,8 @@ int pipe_hip_start(pipe_hip_processor *p)
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     if (p->in_flight) {  // a restarted pipe drops whatever was in flight
-        PH_HIP(hipEventSynchronize(p->done));
-        p->in_flight = false;
+        PH_HIP(hipStreamSynchronize(p->stream));
+        p->in_flight = 0;
     }
     PH_TRY(p->start(p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
@@ -387,7 +394,7 @@ int pipe_hip_flush(pipe_hip_processor *p)
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     PH_HIP(hipStreamSynchronize(p->stream));
-    p->in_flight = false;
+    p->in_flight = 0;
     return p->poll_error();
 }
 
@@ -422,6 +429,8 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
 {
     if (!p || out_cap_frames < 0)
         return PIPE_HIP_EINVAL;
+    if (p->in_flight)  // collect would hand back an older buffer
+        return PIPE_HIP_ESTATE;
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
     return collect_impl(p, out, out_cap_frames, out_frames);
 }
@@ -520,7 +529,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
         const size_t row_in = es * (size_t)r.frames * (size_t)p->cfg.channels;
         for (int i = 0; i < r.count; ++i) {
             const int l = r.first + i;
-            char *dst = static_cast<char *>(p->h_in.p) + r.in_off + row_in * (size_t)i;
+            char *dst = static_cast<char *>(p->stg[0].h_in.p) + r.in_off + row_in * (size_t)i;
             const size_t have = ins[l] ? es * (size_t)in_frames[l] * (size_t)p->cfg.channels : 0;
             if (have)
                 std::memcpy(dst, ins[l], have);
@@ -533,11 +542,11 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
         const size_t row_out = es * (size_t)r.frames * (size_t)p->out_channels();
         int64_t produced = r.frames;
         p->set_window(r.first, r.count == L ? 0 : r.count);
-        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->d_in.p) + r.in_off, static_cast<char *>(p->h_in.p) + r.in_off,
+        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->stg[0].d_in.p) + r.in_off, static_cast<char *>(p->stg[0].h_in.p) + r.in_off,
                               row_in * (size_t)r.count, hipMemcpyHostToDevice, p->stream));
-        PH_TRY(p->run_var(static_cast<char *>(p->d_in.p) + r.in_off, p->cfg.dtype, r.frames,
-                          static_cast<char *>(p->d_out.p) + r.out_off, p->cfg.dtype, r.frames, &produced, p->stream));
-        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->h_out.p) + r.out_off, static_cast<char *>(p->d_out.p) + r.out_off,
+        PH_TRY(p->run_var(static_cast<char *>(p->stg[0].d_in.p) + r.in_off, p->cfg.dtype, r.frames,
+                          static_cast<char *>(p->stg[0].d_out.p) + r.out_off, p->cfg.dtype, r.frames, &produced, p->stream));
+        PH_HIP(hipMemcpyAsync(static_cast<char *>(p->stg[0].h_out.p) + r.out_off, static_cast<char *>(p->stg[0].d_out.p) + r.out_off,
                               row_out * (size_t)r.count, hipMemcpyDeviceToHost, p->stream));
     }
     PH_HIP(hipStreamSynchronize(p->stream));
@@ -547,7 +556,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
             const int l = r.first + i;
             if (!ins[l] || in_frames[l] == 0)
                 continue;
-            std::memcpy(outs[l], static_cast<const char *>(p->h_out.p) + r.out_off + row_out * (size_t)i,
+            std::memcpy(outs[l], static_cast<const char *>(p->stg[0].h_out.p) + r.out_off + row_out * (size_t)i,
                         es * (size_t)in_frames[l] * (size_t)p->out_channels());
         }
     }
@@ -593,8 +602,8 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
     WindowGuard guard{p};
     for (const LineRun &r : runs) {
         int64_t produced = r.frames;
-        char *din = static_cast<char *>(p->d_in.p) + r.in_off;
-        char *dout = static_cast<char *>(p->d_out.p) + r.out_off;
+        char *din = static_cast<char *>(p->stg[0].d_in.p) + r.in_off;
+        char *dout = static_cast<char *>(p->stg[0].d_out.p) + r.out_off;
         p->set_window(r.first, r.count == L ? 0 : r.count);
         PH_TRY(launch_gather_rows(tin + r.first, win + r.first, din, (int)((size_t)r.frames * fb_in / 8), r.count,
                                   p->stream));
@@ -618,30 +627,30 @@ int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t 
     const size_t one = es * (size_t)p->cfg.lines * (size_t)frames * (size_t)p->cfg.channels;
     const size_t cap = es * (size_t)p->cfg.lines * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels;
     // staging: n input slots + 1 output slot, allocated once
-    if (!p->d_in.p) {
-        PH_TRY(p->d_in.alloc(cap * 8));
-        PH_TRY(p->d_out.alloc(cap));
-        PH_TRY(p->h_in.alloc(cap * 8));
-        PH_TRY(p->h_out.alloc(cap));
+    if (!p->stg[0].d_in.p) {
+        PH_TRY(p->stg[0].d_in.alloc(cap * 8));
+        PH_TRY(p->stg[0].d_out.alloc(cap));
+        PH_TRY(p->stg[0].h_in.alloc(cap * 8));
+        PH_TRY(p->stg[0].h_out.alloc(cap));
     }
     const void *d_ins[8] = {};
     for (int i = 0; i < n_inputs; ++i) {
         if (!ins[i] && one)
             return PIPE_HIP_EINVAL;
-        char *h = (char *)p->h_in.p + cap * i;
-        char *d = (char *)p->d_in.p + cap * i;
+        char *h = (char *)p->stg[0].h_in.p + cap * i;
+        char *d = (char *)p->stg[0].d_in.p + cap * i;
         if (one) {
             std::memcpy(h, ins[i], one);
             PH_HIP(hipMemcpyAsync(d, h, one, hipMemcpyHostToDevice, p->stream));
         }
         d_ins[i] = d;
     }
-    PH_TRY(mix_run(p, d_ins, n_inputs, p->d_out.p, frames, p->stream));
+    PH_TRY(mix_run(p, d_ins, n_inputs, p->stg[0].d_out.p, frames, p->stream));
     if (one)
-        PH_HIP(hipMemcpyAsync(p->h_out.p, p->d_out.p, one, hipMemcpyDeviceToHost, p->stream));
+        PH_HIP(hipMemcpyAsync(p->stg[0].h_out.p, p->stg[0].d_out.p, one, hipMemcpyDeviceToHost, p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
     if (one)
-        std::memcpy(out, p->h_out.p, one);
+        std::memcpy(out, p->stg[0].h_out.p, one);
     return PIPE_HIP_OK;
 }
 

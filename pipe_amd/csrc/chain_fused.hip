@@ -192,8 +192,9 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
 }  // namespace
 
 struct Plan::Impl {
-    DevBuf rec, mats, seg_state, err, prof;
-    PinnedBuf h_tab;  // staging of the two tables
+    DevBuf rec, mats[2], seg_state, err, prof;
+    int cur_mats = 0;
+    AsyncUpload upload;  // pinned staging of the matrices
     std::vector<double> coeffs;
     int S = 0, H = -1;
     bool has_gain = false;
@@ -247,17 +248,18 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     I.D = D;
     std::memcpy(I.c1.c, coeffs, sizeof(double) * 5 * (S < 1 ? S : 1));
     I.c1.D = D;
+    // the matrices are double-buffered on the device and staged through pinned memory: a
+    // coefficient mutation uploads them on the launch stream, nothing waits for the device
     const size_t bytes = sizeof(double) * ols::kMatCount * kMaxN2 * kMaxN2;
-    if (!I.mats.p) {
-        PH_TRY(I.mats.alloc(bytes));
-        PH_TRY(I.h_tab.alloc(bytes));
+    if (!I.mats[0].p) {
+        PH_TRY(I.mats[0].alloc(bytes));
+        PH_TRY(I.mats[1].alloc(bytes));
         PH_TRY(I.err.alloc(sizeof(int)));
         PH_HIP(hipMemsetAsync(I.err.p, 0, sizeof(int), s));
-    } else {
-        // the staging block may still be in flight for an earlier upload
-        PH_HIP(hipStreamSynchronize(s));
     }
-    double *h = static_cast<double *>(I.h_tab.p);
+    void *host = nullptr;
+    PH_TRY(I.upload.stage(bytes, &host));
+    double *h = static_cast<double *>(host);
     const size_t mm = (size_t)n * n;
     Mat ak = identity(n);
     for (int j = 0; j <= 16; ++j) {
@@ -278,7 +280,8 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
             w = mul(w, T[32]);
         }
     }
-    PH_HIP(hipMemcpyAsync(I.mats.p, h, sizeof(double) * ols::kMatCount * mm, hipMemcpyHostToDevice, s));
+    I.cur_mats ^= 1;
+    PH_TRY(I.upload.commit(I.mats[I.cur_mats].p, sizeof(double) * ols::kMatCount * mm, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);
     I.S = S;
     I.H = H;
@@ -401,7 +404,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     if (I.seg_state.bytes < seg_bytes)
         PH_TRY(I.seg_state.alloc(seg_bytes));
     fa.seg_state = static_cast<double *>(I.seg_state.p);
-    fa.mats = static_cast<const double *>(I.mats.p);
+    fa.mats = static_cast<const double *>(I.mats[I.cur_mats].p);
     fa.err = static_cast<int *>(I.err.p);
 #ifdef PH_FUSE_PROF
     if (!I.prof.p)

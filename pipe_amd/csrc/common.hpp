@@ -87,6 +87,43 @@ struct PinnedBuf {
     PinnedBuf &operator=(const PinnedBuf &) = delete;
 };
 
+// A parameter upload that never stops the device: two pinned staging slots used in turn, a
+// hipMemcpyAsync on the stream the handle's launches go to, an event per slot so that the host only
+// waits when it wants a slot whose previous upload has not left yet.  (mutable.Mutation bodies
+// run between two buffers of ONE component, pipe.go:433; other Lines on the same device must not
+// feel them.)
+struct AsyncUpload {
+    PinnedBuf slot[2];
+    hipEvent_t left[2] = {nullptr, nullptr};
+    int next = 0;
+    ~AsyncUpload()
+    {
+        for (hipEvent_t e : left)
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+    // host memory for `bytes` of the next upload
+    int stage(size_t bytes, void **host)
+    {
+        if (slot[next].bytes < bytes)
+            PH_TRY(slot[next].alloc(bytes));
+        if (!left[next])
+            PH_HIP(hipEventCreateWithFlags(&left[next], hipEventDisableTiming));
+        else
+            PH_HIP(hipEventSynchronize(left[next]));  // normally long done
+        *host = slot[next].p;
+        return PIPE_HIP_OK;
+    }
+    // queue the copy of what stage() handed out
+    int commit(void *dst, size_t bytes, hipStream_t s)
+    {
+        PH_HIP(hipMemcpyAsync(dst, slot[next].p, bytes, hipMemcpyHostToDevice, s));
+        PH_HIP(hipEventRecord(left[next], s));
+        next ^= 1;
+        return PIPE_HIP_OK;
+    }
+};
+
 // hipEvent bracket around the dominant kernel of a handle (pipe_hip_set_profiling).
 class KernelTimer {
 public:
@@ -125,14 +162,20 @@ struct pipe_hip_processor {
     pipehip::KernelTimer timer;
     const char *last_kernel = "";
 
-    // host<->device staging for the ProcessFunc form (lazily sized)
-    pipehip::DevBuf d_in, d_out;
-    pipehip::PinnedBuf h_in, h_out;
-    void *hd_in = nullptr, *hd_out = nullptr;  // device aliases of h_in / h_out (zero-copy path)
-    pipehip::PinnedBuf line_tab;               // pointer / length tables of process_lines_pinned
-    hipEvent_t done = nullptr;
-    bool in_flight = false;
-    int32_t in_flight_out_frames = 0;
+    // host<->device staging for the ProcessFunc form (lazily sized).  Two slots: buffer k + 1 may
+    // be submitted while buffer k is still on the device (pipe_hip_submit / pipe_hip_collect)
+    struct Staging {
+        pipehip::DevBuf d_in, d_out;
+        pipehip::PinnedBuf h_in, h_out;
+        void *hd_in = nullptr, *hd_out = nullptr;  // device aliases of h_in / h_out (zero-copy path)
+        hipEvent_t done = nullptr;
+        int32_t out_frames = 0;
+    };
+    Staging stg[2];
+    int submit_slot = 0;   // the slot the next submit fills
+    int in_flight = 0;     // buffers submitted and not collected (0..2); the oldest sits in
+                           // slot (submit_slot - in_flight) & 1
+    pipehip::PinnedBuf line_tab;  // pointer / length tables of process_lines_pinned
     bool owned_by_chain = false;
     // set by a chain for a stage whose float64 output feeds a chain that ends in float32:
     // the stage may then use a form that is exact to O(1e-16) instead of bit-exact
@@ -228,7 +271,7 @@ struct pipe_hip_processor {
     virtual int poll_error() { return PIPE_HIP_OK; }
 
     int init_common(const pipe_hip_config *c);
-    int ensure_staging();
+    int ensure_staging(int slot = 0);
     int select_device() const;
 };
 

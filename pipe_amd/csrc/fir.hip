@@ -420,13 +420,20 @@ public:
         }
         if (param != PIPE_HIP_PARAM_TAPS || count != N_ || !values)
             return PIPE_HIP_EINVAL;
-        // double-buffered: launches already queued keep reading the old copy
-        PH_HIP(hipDeviceSynchronize());
+        // Double-buffered on the device: launches already queued keep reading the old copy, the
+        // next launch reads the new one.  The upload is a hipMemcpyAsync from pinned staging on
+        // the stream this handle's launches go to -- stream order does the rest; nothing waits
+        // for the device, and other handles on it (other Lines) do not notice (mutable.go:40-94,
+        // pipe.go:433).  A caller that moves the handle between streams orders them itself.
+        const size_t bytes = sizeof(double) * (size_t)N_;
+        void *host = nullptr;
+        PH_TRY(upload_.stage(bytes, &host));
+        std::memcpy(host, values, bytes);
         const int nxt = cur_taps_ ^ 1;
-        PH_HIP(hipMemcpy(taps_[nxt].p, values, sizeof(double) * (size_t)N_, hipMemcpyHostToDevice));
+        PH_TRY(upload_.commit(taps_[nxt].p, bytes, last_stream()));
         cur_taps_ = nxt;
         if (ols_)
-            PH_TRY(ols_->set_taps(values));
+            PH_TRY(ols_->set_taps(values, last_stream()));
         return PIPE_HIP_OK;
     }
 
@@ -435,6 +442,7 @@ public:
     {
         if (frames <= 0)
             return PIPE_HIP_OK;
+        last_stream_ = s;
         // a window of Lines (pipe_hip_process_lines with ragged lengths): the per-Line history
         // slices of exactly those Lines
         const int nl = active_lines();
@@ -493,7 +501,11 @@ public:
         v->min_items = ols_min_items();
         return true;
     }
-    int fuse_commit_fir(hipStream_t s) override { return flip_history(s); }
+    int fuse_commit_fir(hipStream_t s) override
+    {
+        last_stream_ = s;
+        return flip_history(s);
+    }
 
 private:
     // enough 1024-point transforms to give every SIMD of the chip a few
@@ -658,8 +670,12 @@ private:
         }
     }
 
+    hipStream_t last_stream() const { return last_stream_ ? last_stream_ : stream; }
+
     int N_ = 0, H_ = 0;
     int cus_ = 256;
+    hipStream_t last_stream_ = nullptr;  // where the last launch went: parameter uploads follow it
+    AsyncUpload upload_;
     DevBuf taps_[2];
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;

@@ -29,6 +29,7 @@
 // tables are loaded; waves walk (Line, channel pair, tile) items on their own, 16 per CU.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -422,22 +423,51 @@ bool Plan::supports(int ntaps, int channels)
     return ntaps >= 16 && ntaps <= 512;
 }
 
-static void tap_spectrum(const double *taps, int N, std::vector<double> *out)
+// H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2 (the kernels take the upper half from
+// H[M - k] = conj(H[k]): real taps), written as interleaved re/im doubles.  A radix-2 transform of
+// the zero-padded taps in long double: microseconds, where the defining double sum (513 x N cosl /
+// sinl) took milliseconds inside a mutation.
+static void tap_spectrum(const double *taps, int N, double *out)
 {
-    // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2; the kernel takes the upper
-    // half from H[M - k] = conj(H[k]) (real taps)
-    out->assign(2 * (kHalf + 1), 0.0);
-    for (int k = 0; k < kHalf; ++k) {
-        long double sr = 0, si = 0;
-        for (int n = 0; n < N; ++n) {
-            const int e = (int)(((int64_t)n * k) % kM);
-            const long double ang = -2.0L * (long double)kPi * e / kM;
-            sr += (long double)taps[n] * cosl(ang);
-            si += (long double)taps[n] * sinl(ang);
+    typedef long double ld;
+    static std::vector<ld> wr, wi;  // exp(-2 pi i j / M), j < M / 2 (computed once; handles are
+                                    // created and mutated from the pipe's own threads one at a time
+                                    // per component, but any thread may get here first)
+    static std::once_flag once;
+    std::call_once(once, [] {
+        wr.resize(kM / 2);
+        wi.resize(kM / 2);
+        for (int j = 0; j < kM / 2; ++j) {
+            const ld ang = -2.0L * (ld)kPi * j / kM;
+            wr[j] = cosl(ang);
+            wi[j] = sinl(ang);
         }
-        (*out)[2 * k] = (double)(sr / kM);
-        (*out)[2 * k + 1] = (double)(si / kM);
+    });
+    std::vector<ld> re(kM, 0.0L), im(kM, 0.0L);
+    for (int n = 0; n < kM; ++n) {  // bit-reversed input order
+        int r = 0;
+        for (int b = 0; b < 10; ++b)
+            r |= ((n >> b) & 1) << (9 - b);
+        re[r] = n < N ? (ld)taps[n] : 0.0L;
     }
+    for (int len = 2; len <= kM; len <<= 1) {
+        const int half = len / 2, step = kM / len;
+        for (int i = 0; i < kM; i += len)
+            for (int j = 0; j < half; ++j) {
+                const ld cr = wr[j * step], ci = wi[j * step];
+                const ld xr = re[i + j + half], xi = im[i + j + half];
+                const ld tr = xr * cr - xi * ci, ti = xr * ci + xi * cr;
+                re[i + j + half] = re[i + j] - tr;
+                im[i + j + half] = im[i + j] - ti;
+                re[i + j] += tr;
+                im[i + j] += ti;
+            }
+    }
+    for (int k = 0; k < kHalf; ++k) {
+        out[2 * k] = (double)(re[k] / kM);
+        out[2 * k + 1] = (double)(im[k] / kM);
+    }
+    out[2 * kHalf] = out[2 * kHalf + 1] = 0.0;  // the pad entry
 }
 
 int Plan::init(int device, const double *taps, int ntaps)
@@ -469,15 +499,21 @@ int Plan::init(int device, const double *taps, int ntaps)
     PH_HIP(hipMemcpy(impl_->tw1.p, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
     PH_HIP(hipMemcpy(impl_->tw2.p, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
     PH_TRY(init_ols32_tables(impl_));
-    return set_taps(taps);
+    PH_TRY(set_taps(taps, nullptr));
+    PH_HIP(hipStreamSynchronize(nullptr));
+    return PIPE_HIP_OK;
 }
 
-int Plan::set_taps(const double *taps)
+int Plan::set_taps(const double *taps, hipStream_t s)
 {
-    std::vector<double> h;
-    tap_spectrum(taps, impl_->N, &h);
+    // double-buffered on the device (launches already queued keep the old spectrum), staged
+    // through pinned memory and copied on the handle's stream: no device-wide wait
+    const size_t bytes = sizeof(double) * 2 * (kHalf + 1);
+    void *host = nullptr;
+    PH_TRY(impl_->upload.stage(bytes, &host));
+    tap_spectrum(taps, impl_->N, static_cast<double *>(host));
     const int nxt = impl_->cur ^ 1;
-    PH_HIP(hipMemcpy(impl_->hperm[nxt].p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    PH_TRY(impl_->upload.commit(impl_->hperm[nxt].p, bytes, s));
     impl_->cur = nxt;
     return PIPE_HIP_OK;
 }

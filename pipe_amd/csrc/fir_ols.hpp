@@ -19,8 +19,9 @@ public:
     // taps the FFT path is built for (otherwise the direct form is used)
     static bool supports(int ntaps, int channels);
     int init(int device, const double *taps, int ntaps);
-    // double-buffered like the direct form's taps: queued launches keep the old spectrum
-    int set_taps(const double *taps);
+    // double-buffered like the direct form's taps: queued launches keep the old spectrum; the
+    // upload is asynchronous on `s` (the stream the handle's launches go to)
+    int set_taps(const double *taps, hipStream_t s);
     // work items (wave-sized 1024-point transforms) a call of this size launches
     int64_t items(int64_t frames, int channels, int lines) const;
     // advance every Line by `frames` frames; `hist` = the (N-1) frames before the call

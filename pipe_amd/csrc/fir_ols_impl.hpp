@@ -11,6 +11,7 @@ struct Plan::Impl {
     DevBuf tw1, tw2;    // fir_ols.hip: W1024^(n1 k2) [16][64], W64^(a d) [4][16]
     DevBuf tw32;        // fir_ols32.hip: W1024^(k n) [32][32]
     DevBuf hperm[2];    // tap spectrum H[0..512] / 1024, double-buffered
+    AsyncUpload upload; // pinned staging of the spectrum uploads
     int cur = 0;
     int N = 0;
     int cus = 256;

@@ -75,14 +75,23 @@ def config1_per_call():
             emit(config=1, what="ProcessFunc form: pipe_hip_process, one 4096x2 buffer, H2D+kernel+D2H, synchronous",
                  io=str(np.dtype(dtype)), us_per_buffer=round(dt * 1e6, 2),
                  msamples_per_s=round(F * C / dt / 1e6, 2), realtime_factor_48k=round(F / 48000 / dt, 1))
-            # depth-1 pipelining: submit k+1 while k is in flight is not allowed (capacity 1), so the
-            # overlap available is host work between submit and collect
+            # the asynchronous form: buffer k + 1 is submitted while buffer k is on the device
+            # (two staging slots per handle), so staging / launch overlap kernels and transfers
             def sc():
                 p.submit(xin)
                 p.collect()
             dt2 = timed(sc, 300, 20)
-            emit(config=1, what="submit + collect (same buffer)", io=str(np.dtype(dtype)),
+            emit(config=1, what="submit + collect, one buffer in flight", io=str(np.dtype(dtype)),
                  us_per_buffer=round(dt2 * 1e6, 2))
+            p.submit(xin)
+
+            def pipelined():
+                p.submit(xin)
+                p.collect()
+            dt3 = timed(pipelined, 300, 20)
+            p.collect()
+            emit(config=1, what="submit(k+1) before collect(k): two buffers in flight", io=str(np.dtype(dtype)),
+                 us_per_buffer=round(dt3 * 1e6, 2), msamples_per_s=round(F * C / dt3 / 1e6, 2))
 
 
 def batch(config, what, proc, d_in, d_out, frames, samples, reps=20):

@@ -342,26 +342,109 @@ def test_chain_matches_oracle_pipe_loop():
 
 
 # ------------------------------------------------------------------ async form, errors
-def test_submit_collect_depth_one():
+def test_submit_collect_two_in_flight():
+    """pipe_hip_submit / pipe_hip_collect: the asynchronous form of ProcessFunc.  Like a link of
+    fitting.Async (one message queued + one in the receiver's hand, fitting.go:56-60) a handle
+    takes TWO buffers in flight: buffer k + 1 is staged and launched while buffer k is still on the
+    device.  collect() hands buffers back oldest first; a third submit, a collect with nothing in
+    flight and a synchronous process() over buffers in flight are ESTATE."""
     from pipe_amd._lib import ESTATE, PipeHipError
     F, C = 1024, 2
     h = synth.fir_lowpass_taps(64)
-    x = sig(11, 4 * F, C, np.float32)
+    x = sig(11, 6 * F, C, np.float32)
     ref = O.Fir(h, C)
+    want = [ref.process(x[k * F:(k + 1) * F].astype(np.float64)).reshape(F, C).astype(np.float32) for k in range(6)]
     with P.Fir(h, F, C) as p:
         p.start()
         with pytest.raises(PipeHipError) as e:
             p.collect()
         assert e.value.status == ESTATE
-        for k in range(4):
+        p.submit(x[0:F])
+        p.submit(x[F:2 * F])                       # second buffer while the first is in flight
+        with pytest.raises(PipeHipError) as e:
+            p.submit(x[2 * F:3 * F])               # a third is refused
+        assert e.value.status == ESTATE
+        with pytest.raises(PipeHipError) as e:
+            p.process(x[2 * F:3 * F])              # and so is the synchronous form
+        assert e.value.status == ESTATE
+        for k in range(2, 6):                      # steady state: collect k - 2, submit k
+            assert np.array_equal(p.collect(), want[k - 2])
             p.submit(x[k * F:(k + 1) * F])
-            if k == 0:
-                with pytest.raises(PipeHipError) as e:
-                    p.submit(x[:F])  # capacity 1, like fitting.Async (fitting.go:56-60)
-                assert e.value.status == ESTATE
-            got = p.collect()
-            want = ref.process(x[k * F:(k + 1) * F].astype(np.float64)).reshape(F, C).astype(np.float32)
-            assert np.array_equal(got, want)
+        assert np.array_equal(p.collect(), want[4])
+        assert np.array_equal(p.collect(), want[5])
+        with pytest.raises(PipeHipError) as e:
+            p.collect()
+        assert e.value.status == ESTATE
+        # a short last buffer in flight behind a full one
+        ref2 = O.Fir(h, C)
+        p.start()
+        p.submit(x[:F])
+        p.submit(x[F:F + 100])
+        assert np.array_equal(p.collect(), ref2.process(x[:F].astype(np.float64)).reshape(F, C).astype(np.float32))
+        got = p.collect()
+        assert got.shape == (100, C)
+        assert np.array_equal(got, ref2.process(x[F:F + 100].astype(np.float64)).reshape(100, C).astype(np.float32))
+
+
+def test_set_taps_does_not_stall_other_handles():
+    """A parameter mutation is an asynchronous upload on the mutated handle's own stream
+    (pipe.go:433, mutable.go:40-94): another Line streaming through ANOTHER handle on the same
+    device must not feel it.  Handle A swaps its taps before every buffer while handle B streams;
+    B's per-buffer latency stays where it is when A only streams, and both stay bit-exact."""
+    import threading
+    import time
+    F, C, N, K = 4096, 2, 256, 300
+    h1 = synth.fir_lowpass_taps(N, f32_rounded=True)
+    h2 = synth.fir_lowpass_taps(N, fc=0.1, f32_rounded=True)
+    xa = sig(21, F, C, np.float32)
+    xb = sig(22, 4 * F, C, np.float32)
+
+    def run(mutate):
+        lat = []
+        with P.Fir(h1, F, C) as a, P.Fir(h1, F, C) as b:
+            a.start()
+            b.start()
+            stop = threading.Event()
+            outs_a = []
+
+            def loop_a():
+                k = 0
+                while not stop.is_set():
+                    if mutate:
+                        a.set_taps(h2 if k % 2 == 0 else h1)
+                    y = a.process(xa)
+                    if k < 4:
+                        outs_a.append(y)
+                    k += 1
+
+            t = threading.Thread(target=loop_a)
+            t.start()
+            outs_b = []
+            for k in range(K):
+                t0 = time.perf_counter()
+                y = b.process(xb[(k % 4) * F:(k % 4 + 1) * F])
+                lat.append(time.perf_counter() - t0)
+                if k < 4:
+                    outs_b.append(y)
+            stop.set()
+            t.join()
+        return float(np.median(lat[20:])), outs_a, outs_b
+
+    base, _, ob0 = run(False)
+    mut, oa, ob = run(True)
+    # B: bit-exact in both runs
+    ref = O.Fir(h1, C)
+    for k in range(4):
+        w = ref.process(xb[k * F:(k + 1) * F].astype(np.float64)).reshape(F, C).astype(np.float32)
+        assert np.array_equal(ob0[k], w) and np.array_equal(ob[k], w)
+    # A: buffer k was filtered with the taps set just before it (h2, h1, h2, h1), history carried
+    ra = O.Fir(h1, C)
+    for k in range(4):
+        ra.set_taps(h2 if k % 2 == 0 else h1)
+        assert np.array_equal(oa[k], ra.process(xa.astype(np.float64)).reshape(F, C).astype(np.float32))
+    print(f"\n[set_taps isolation] B median per-buffer latency: {base * 1e6:.1f} us alone+A streaming, "
+          f"{mut * 1e6:.1f} us with A mutating every buffer")
+    assert mut <= 1.10 * base + 3e-6, (base, mut)
 
 
 def test_argument_errors():
