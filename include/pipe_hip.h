@@ -123,6 +123,11 @@ int pipe_hip_output_properties(const pipe_hip_processor *p, int32_t *channels,
 /* StartFunc (pipe.go:82-83; called at run.go:64-74,177,201): zero all per-Line
  * state.  A pipe may be started again (pipe_test.go:108-131). */
 int pipe_hip_start(pipe_hip_processor *p);
+/* StartFunc of Lines [first, first + count) of a handle with cfg.lines > 1 only: a Line that
+ * joins a RUNNING batch handle (Pipe.AddLine, pipe.go:260-300; multiLineExecutor.addRoute starts
+ * the new Line's components between two passes, run.go:134-145) begins from silence while the
+ * other Lines keep their state.  Fixed-rate processors; PIPE_HIP_EINVAL otherwise. */
+int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count);
 /* FlushFunc (pipe.go:84-86; run.go:54-62): drain the handle's stream. */
 int pipe_hip_flush(pipe_hip_processor *p);
 /* Releases device and pinned memory.  (Go has no destructor hook; the shim ties

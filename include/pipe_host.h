@@ -42,6 +42,9 @@ typedef struct pipe_host_proc_desc {
     int32_t err_on_call, err_on_start, err_on_flush, err_on_make;
     int32_t mutate_gain;     /* HIP_GAIN only: push SetGain(mutated_gain) as a Start initializer */
     double mutated_gain;
+    int32_t insert_before_pass; /* RUN_BATCHED only: > 0 = the Line is bound WITHOUT this Processor and it is
+                                   inserted while the pipe runs, before that pass (Pipe.InsertProcessor,
+                                   pipe.go:302-365) */
 } pipe_host_proc_desc;
 
 typedef struct pipe_host_line_desc {
@@ -56,6 +59,8 @@ typedef struct pipe_host_line_desc {
     pipe_host_proc_desc procs[PIPE_HOST_MAX_PROCS];
     int32_t sink_discard;
     int32_t sink_err_on_call, sink_err_on_start, sink_err_on_flush, sink_err_on_make;
+    int32_t join_before_pass; /* RUN_BATCHED only: > 0 = the Line is not bound at the start but added to the
+                                 running pipe before that pass (Pipe.AddLine, pipe.go:260-300) */
 } pipe_host_line_desc;
 
 typedef struct pipe_host_counter {

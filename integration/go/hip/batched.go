@@ -1,0 +1,144 @@
+package hip
+
+// Many Lines, one launch per pass (SURVEY.md 8 f4).
+//
+// pipe.Run's multiLineExecutor is Line-major (run.go:112-132): Line 0's Source, Processors and
+// Sink, then Line 1's ... -- L Lines cost L ProcessFunc calls = L launches per pass.  A Batch is
+// ONE device handle with cfg.lines = L behind the Processors of L Lines; with the stage-major
+// executor of ../pipe_patch/run_batched.go every pass advances all of them with one
+// pipe_hip_process_lines call.  SOURCE ONLY, never compiled (see hip.go).
+
+/*
+#include "pipe_hip.h"
+*/
+import "C"
+
+import (
+	"context"
+	"errors"
+	"runtime"
+	"unsafe"
+
+	"pipelined.dev/pipe"
+	"pipelined.dev/pipe/mutable"
+	"pipelined.dev/signal"
+)
+
+// Batch is the shared handle of `lines` Lines running the same fixed-rate chain.
+type Batch struct {
+	stages []*Stage
+	lines  int
+	opts   Options
+
+	p                 *C.pipe_hip_processor
+	bufferSize, chans int
+	mctx              mutable.Context
+	// per slot: pinned staging (the pool buffers of signal v0.10.0 are not pinned; a pool built
+	// on pipe_hip_host_alloc would let pipe_hip_process_lines_pinned read them in place)
+	in, out   [][]float64
+	inP, outP []unsafe.Pointer
+	frames    []C.int32_t
+	written   []C.int32_t
+	live      []bool
+}
+
+// BatchedChain: stages as in Chain; Allocator(slot) is the allocator of Line `slot`.
+func BatchedChain(o Options, lines int, stages ...*Stage) *Batch {
+	return &Batch{stages: stages, lines: lines, opts: o}
+}
+
+// BatchProcessor is what the stage-major executor looks for on a Processor (an interface the
+// patch adds to package pipe): Processors with the same Group advance together.
+type BatchProcessor interface {
+	Group() *Batch
+	Slot() int
+}
+
+func (b *Batch) bind(mctx mutable.Context, bufferSize int, in pipe.SignalProperties) error {
+	if b.p != nil {
+		if bufferSize != b.bufferSize || in.Channels != b.chans {
+			return errors.New("hip.Batch: every Line must have the same buffer size and channels")
+		}
+		return nil
+	}
+	cfg := b.opts.config(bufferSize, in.Channels, b.lines)
+	chain, err := Chain(b.opts, b.stages...).create(&cfg)
+	if err != nil {
+		return err
+	}
+	b.p, b.bufferSize, b.chans, b.mctx = chain, bufferSize, in.Channels, mctx
+	n := bufferSize * in.Channels
+	for i := 0; i < b.lines; i++ {
+		hi, pi, err := pinned(n)
+		if err != nil {
+			return err
+		}
+		ho, po, err := pinned(n)
+		if err != nil {
+			return err
+		}
+		b.in, b.inP = append(b.in, hi), append(b.inP, pi)
+		b.out, b.outP = append(b.out, ho), append(b.outP, po)
+	}
+	b.frames = make([]C.int32_t, b.lines)
+	b.written = make([]C.int32_t, b.lines)
+	b.live = make([]bool, b.lines)
+	return nil
+}
+
+// Allocator of Line `slot`.  The returned Processor's ProcessFunc refuses to run: these
+// Processors only run under pipe.RunBatched, which calls ProcessLines once per pass.
+func (b *Batch) Allocator(slot int) pipe.ProcessorAllocatorFunc {
+	return func(mctx mutable.Context, bufferSize int, in pipe.SignalProperties) (pipe.Processor, error) {
+		if err := b.bind(mctx, bufferSize, in); err != nil {
+			return pipe.Processor{}, err
+		}
+		return pipe.Processor{
+			SignalProperties: in, // a fixed-rate chain keeps rate and channels
+			StartFunc:        func(context.Context) error { return status(C.pipe_hip_start(b.p), "start") },
+			FlushFunc:        func(context.Context) error { return status(C.pipe_hip_flush(b.p), "flush") },
+			ProcessFunc: func(signal.Floating, signal.Floating) (int, error) {
+				return 0, errors.New("hip.Batch: run the Lines with pipe.RunBatched")
+			},
+			// Batch: b, BatchSlot: slot   <- the two fields the patch adds to pipe.Processor
+		}, nil
+	}
+}
+
+// ProcessLines is the body of one stage-major pass: ins[slot] / outs[slot] are the pool buffers
+// of the Lines that delivered a buffer this pass (nil: the Line has ended).  Every Line advances
+// by exactly its own frames (a short read mid-stream included, pipe.go:404-406).
+func (b *Batch) ProcessLines(ins, outs []signal.Floating) ([]int, error) {
+	inPtrs := make([]unsafe.Pointer, b.lines)
+	outPtrs := make([]unsafe.Pointer, b.lines)
+	for i := 0; i < b.lines; i++ {
+		b.frames[i], b.live[i] = 0, ins[i] != nil
+		if !b.live[i] {
+			continue
+		}
+		b.frames[i] = C.int32_t(read(ins[i], b.in[i]))
+		inPtrs[i], outPtrs[i] = b.inP[i], b.outP[i]
+	}
+	st := C.pipe_hip_process_lines_pinned(b.p, (*unsafe.Pointer)(unsafe.Pointer(&inPtrs[0])), &b.frames[0],
+		(*unsafe.Pointer)(unsafe.Pointer(&outPtrs[0])), &b.written[0])
+	runtime.KeepAlive(inPtrs)
+	runtime.KeepAlive(outPtrs)
+	if err := status(st, "process_lines"); err != nil {
+		return nil, err
+	}
+	n := make([]int, b.lines)
+	for i := 0; i < b.lines; i++ {
+		if b.live[i] {
+			n[i] = int(b.written[i])
+			write(b.out[i][:n[i]*b.chans], outs[i])
+		}
+	}
+	return n, nil
+}
+
+// Mutations address the shared handle: every Line of the group sees them at the same pass.
+func (b *Batch) SetGain(g float64) mutable.Mutation {
+	return b.mctx.Mutate(func() error {
+		return status(C.pipe_hip_set_param(b.p, C.PIPE_HIP_PARAM_GAIN, (*C.double)(unsafe.Pointer(&g)), 1), "set gain")
+	})
+}

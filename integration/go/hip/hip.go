@@ -1,0 +1,332 @@
+// Package hip provides pipe.ProcessorAllocatorFuncs whose ProcessFunc bodies run on an AMD
+// MI355X through libpipe_hip.so (C ABI: include/pipe_hip.h).
+//
+// SOURCE ONLY: the image this repository is built in has no Go toolchain and the reference's
+// buffer package pipelined.dev/signal v0.10.0 is not vendored, so this file has never been
+// compiled.  It is the binding a maintainer adds next to the reference; nothing in pipe.go,
+// line.go, run.go, internal/fitting or mutable changes.  The same sequence of C-ABI calls is
+// exercised from compiled code by the C++ host mirror (pipe_amd/csrc/host/hip_processors.cpp)
+// and by examples/fir_stream.c.
+//
+// Every constructor returns a *Stage.  Stage.Allocator() is the pipe.ProcessorAllocatorFunc
+// (line.go:26-30); once the pipe has bound the Line (pipe.New / pipe.Run call the allocator,
+// line.go:62-104) the Stage holds the device handle and hands out mutations for it:
+//
+//	fir := hip.Fir(taps, hip.Options{Device: 0})
+//	line := pipe.Line{Source: src, Processors: pipe.Processors(fir.Allocator()), Sink: sink}
+//	p, _ := pipe.New(4096, line)
+//	errc := p.Start(ctx)
+//	p.Push(fir.SetTaps(newTaps))      // applied right before the ProcessFunc of the buffer
+//	err := pipe.Wait(errc)            // it travels with (pipe.go:433)
+package hip
+
+/*
+#cgo CFLAGS:  -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../pipe_amd/lib -lpipe_hip -Wl,-rpath,${SRCDIR}/../../../pipe_amd/lib
+#include <stdlib.h>
+#include "pipe_hip.h"
+*/
+import "C"
+
+import (
+	"context"
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"pipelined.dev/pipe"
+	"pipelined.dev/pipe/mutable"
+	"pipelined.dev/signal"
+)
+
+// Options of every allocator.
+type Options struct {
+	Device int // HIP device ordinal; Line i of an n-GPU host takes i % n (SURVEY.md 8e)
+}
+
+// Stage is one GPU Processor: its allocator before the Line is bound, its handle afterwards.
+type Stage struct {
+	create func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error)
+	opts   Options
+
+	// set by the allocator (bind time)
+	p    *C.pipe_hip_processor
+	mctx mutable.Context // the context the pipe chose for this component (line.go:133-151
+	// overwrite whatever the allocator returns, so mutations must be made with THIS one)
+	inH, outH   []float64      // pinned staging, bufferSize * channels each
+	inP, outP   unsafe.Pointer // their C addresses
+	outChannels int
+}
+
+func status(st C.int, what string) error {
+	if st == C.PIPE_HIP_OK {
+		return nil
+	}
+	msg := C.GoString(C.pipe_hip_strerror(st))
+	if st == C.PIPE_HIP_EHIP {
+		return fmt.Errorf("pipe_hip %s: %s (hipError %d)", what, msg, int(C.pipe_hip_last_hip_error()))
+	}
+	return fmt.Errorf("pipe_hip %s: %s", what, msg)
+}
+
+func pinned(n int) ([]float64, unsafe.Pointer, error) {
+	var p unsafe.Pointer
+	if err := status(C.pipe_hip_host_alloc(C.int64_t(n*8), &p), "host_alloc"); err != nil {
+		return nil, nil, err
+	}
+	return unsafe.Slice((*float64)(p), n), p, nil
+}
+
+func doubles(v []float64) *C.double {
+	if len(v) == 0 {
+		return nil
+	}
+	return (*C.double)(unsafe.Pointer(&v[0]))
+}
+
+// The pipe carries float64 buffers (pipe.go:394,437): dtype F64, one Line per handle.
+func (o Options) config(bufferSize, channels, lines int) C.pipe_hip_config {
+	return C.pipe_hip_config{
+		device: C.int32_t(o.Device), buffer_size: C.int32_t(bufferSize), channels: C.int32_t(channels),
+		dtype: C.PIPE_HIP_F64, lines: C.int32_t(lines), max_batch: 1,
+	}
+}
+
+// signal.Floating <-> []float64.  v0.10.0 exposes per-sample accessors (the reference itself
+// fills buffers with SetSample, mock/mock.go:100-102); a raw-slice accessor would remove this hop.
+func read(in signal.Floating, dst []float64) int {
+	n := in.Length() * in.Channels()
+	for i := 0; i < n; i++ {
+		dst[i] = in.Sample(i)
+	}
+	return in.Length()
+}
+
+func write(src []float64, out signal.Floating) {
+	for i, v := range src {
+		out.SetSample(i, v)
+	}
+}
+
+// Allocator is the pipe.ProcessorAllocatorFunc of this stage (line.go:26-30).  It may run while
+// the pipe is running (pipe.go:314-321): everything it touches belongs to this Stage.
+func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
+	return func(mctx mutable.Context, bufferSize int, in pipe.SignalProperties) (pipe.Processor, error) {
+		cfg := s.opts.config(bufferSize, in.Channels, 1)
+		p, err := s.create(&cfg)
+		if err != nil {
+			return pipe.Processor{}, err // pipe.New wraps it: "processor: %w" (line.go:72-74)
+		}
+		var ch, up, down C.int32_t
+		if err := status(C.pipe_hip_output_properties(p, &ch, &up, &down), "output_properties"); err != nil {
+			C.pipe_hip_destroy(p)
+			return pipe.Processor{}, err
+		}
+		s.p, s.mctx, s.outChannels = p, mctx, int(ch)
+		if s.inH, s.inP, err = pinned(bufferSize * in.Channels); err != nil {
+			return pipe.Processor{}, err
+		}
+		if s.outH, s.outP, err = pinned(bufferSize * int(ch)); err != nil {
+			return pipe.Processor{}, err
+		}
+		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
+		return pipe.Processor{
+			// the stage's OUTPUT properties: they size the out pool (pipe.go:418) and are the
+			// next stage's input (line.go:75)
+			SignalProperties: pipe.SignalProperties{
+				SampleRate: in.SampleRate * signal.Frequency(up) / signal.Frequency(down),
+				Channels:   int(ch),
+			},
+			// run.go:64-74: once, inside the executing goroutine, before the loop; a pipe may be
+			// started again (pipe_test.go:108-131) and pipe_hip_start zeroes the per-Line state.
+			// Every C entry point selects its device itself: goroutines migrate between OS
+			// threads and HIP's current device is per thread, no LockOSThread needed.
+			StartFunc: func(context.Context) error { return status(C.pipe_hip_start(s.p), "start") },
+			// pipe.go:438: one buffer.  `in` is freed by the pipe right after the call
+			// (pipe.go:431) and must not be kept; `out` has Length() == bufferSize.
+			ProcessFunc: func(in, out signal.Floating) (int, error) {
+				n := read(in, s.inH)
+				var written C.int32_t
+				st := C.pipe_hip_process(s.p, s.inP, C.int32_t(n), s.outP, C.int32_t(out.Length()), &written)
+				if err := status(st, "process"); err != nil {
+					return 0, err // the run ends with "error running: %w" (run.go:191-193)
+				}
+				write(s.outH[:int(written)*s.outChannels], out)
+				return int(written), nil // pipe.go:441-443 slices out when written < bufferSize
+			},
+			FlushFunc: func(context.Context) error { return status(C.pipe_hip_flush(s.p), "flush") },
+		}, nil
+	}
+}
+
+// Close releases device and pinned memory (also the finalizer).
+func (s *Stage) Close() {
+	if s.p != nil {
+		C.pipe_hip_destroy(s.p)
+		C.pipe_hip_host_free(s.inP)
+		C.pipe_hip_host_free(s.outP)
+		s.p = nil
+	}
+}
+
+// ---- allocators -----------------------------------------------------------------------------
+
+// Gain: y = x * gain.  Gain(1, o) is the reference's mock.Processor (mock/mock.go:139-157).
+func Gain(gain float64, o Options) *Stage {
+	return &Stage{opts: o, create: func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error) {
+		var p *C.pipe_hip_processor
+		return p, status(C.pipe_hip_gain_create(cfg, C.double(gain), &p), "gain_create")
+	}}
+}
+
+// Fir: direct-form FIR, the same taps for every channel.
+func Fir(taps []float64, o Options) *Stage {
+	taps = append([]float64(nil), taps...)
+	return &Stage{opts: o, create: func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error) {
+		var p *C.pipe_hip_processor
+		st := C.pipe_hip_fir_create(cfg, doubles(taps), C.int32_t(len(taps)), &p)
+		runtime.KeepAlive(taps)
+		return p, status(st, "fir_create")
+	}}
+}
+
+// Biquad: DF2T cascade; coeffs holds {b0, b1, b2, a1, a2} per section.
+func Biquad(coeffs []float64, o Options) *Stage {
+	coeffs = append([]float64(nil), coeffs...)
+	return &Stage{opts: o, create: func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error) {
+		if len(coeffs)%5 != 0 {
+			return nil, errors.New("hip.Biquad: coefficients come in fives")
+		}
+		var p *C.pipe_hip_processor
+		st := C.pipe_hip_biquad_create(cfg, doubles(coeffs), C.int32_t(len(coeffs)/5), &p)
+		runtime.KeepAlive(coeffs)
+		return p, status(st, "biquad_create")
+	}}
+}
+
+// Resampler: rational polyphase, output SampleRate = input * up / down (line.go:38-41 carries
+// it to the next stage and to the sink).  proto has up*tapsPerPhase taps.  An up-sampler emits
+// more frames than it reads, which ProcessFunc cannot express with full buffers (out is
+// bufferSize frames, pipe.go:437-443): feed it at most floor(bufferSize*down/up) frames per
+// buffer (3763 for 4096 at 44.1 -> 48 kHz) or the call fails with "output exceeds buffer capacity".
+func Resampler(proto []float64, tapsPerPhase, up, down int, o Options) *Stage {
+	proto = append([]float64(nil), proto...)
+	return &Stage{opts: o, create: func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error) {
+		var p *C.pipe_hip_processor
+		st := C.pipe_hip_resampler_create(cfg, doubles(proto), C.int32_t(tapsPerPhase), C.int32_t(up),
+			C.int32_t(down), &p)
+		runtime.KeepAlive(proto)
+		return p, status(st, "resampler_create")
+	}}
+}
+
+// Chain: several fixed-rate stages (Fir, Biquad, Gain) as ONE Processor whose intermediates stay
+// on the device (a Line's Processors slice, line.go:17, collapsed into one component).  The
+// stages' own Allocators must not be used as well.
+func Chain(o Options, stages ...*Stage) *Stage {
+	return &Stage{opts: o, create: func(cfg *C.pipe_hip_config) (*C.pipe_hip_processor, error) {
+		raw := make([]*C.pipe_hip_processor, 0, len(stages))
+		destroy := func() {
+			for _, r := range raw {
+				C.pipe_hip_destroy(r)
+			}
+		}
+		for _, st := range stages {
+			p, err := st.create(cfg)
+			if err != nil {
+				destroy()
+				return nil, err
+			}
+			raw = append(raw, p)
+		}
+		var chain *C.pipe_hip_processor
+		st := C.pipe_hip_chain_create(&raw[0], C.int32_t(len(raw)), &chain) // takes ownership
+		runtime.KeepAlive(raw)
+		if err := status(st, "chain_create"); err != nil {
+			destroy()
+			return nil, err
+		}
+		return chain, nil
+	}}
+}
+
+// ---- mutations (mutable/mutable.go:40-48; applied at pipe.go:433, before ProcessFunc) -------------
+
+func (s *Stage) setParam(param C.int32_t, values []float64, what string) mutable.Mutation {
+	values = append([]float64(nil), values...)
+	return s.mctx.Mutate(func() error {
+		st := C.pipe_hip_set_param(s.p, param, doubles(values), C.int32_t(len(values)))
+		runtime.KeepAlive(values)
+		return status(st, what)
+	})
+}
+
+// SetGain / SetTaps / SetCoeffs: take effect for the buffer the mutation travels with and for
+// none already processed.  The upload is asynchronous on the handle's own stream: other Lines on
+// the same device are not stalled.  On a Chain the parameter goes to the first stage that takes it;
+// SetStageParam addresses one stage.
+func (s *Stage) SetGain(g float64) mutable.Mutation {
+	return s.setParam(C.PIPE_HIP_PARAM_GAIN, []float64{g}, "set gain")
+}
+func (s *Stage) SetTaps(taps []float64) mutable.Mutation {
+	return s.setParam(C.PIPE_HIP_PARAM_TAPS, taps, "set taps")
+}
+func (s *Stage) SetCoeffs(c []float64) mutable.Mutation {
+	return s.setParam(C.PIPE_HIP_PARAM_COEFFS, c, "set coeffs")
+}
+
+// SetExact pins the ordered-fma (bit-exact) forms even for float32 batches.
+func (s *Stage) SetExact(on bool) mutable.Mutation {
+	v := 0.0
+	if on {
+		v = 1
+	}
+	return s.setParam(C.PIPE_HIP_PARAM_EXACT, []float64{v}, "set exact")
+}
+
+// SetStageParam: parameter `param` (C.PIPE_HIP_PARAM_*) of stage `stage` of a Chain.
+func (s *Stage) SetStageParam(stage int, param int, values []float64) mutable.Mutation {
+	values = append([]float64(nil), values...)
+	return s.mctx.Mutate(func() error {
+		st := C.pipe_hip_chain_set_param(s.p, C.int32_t(stage), C.int32_t(param), doubles(values),
+			C.int32_t(len(values)))
+		runtime.KeepAlive(values)
+		return status(st, "chain set param")
+	})
+}
+
+// ---- n-input mix -----------------------------------------------------------------------------
+// The reference has no signal merger (merger.go merges error channels), and ProcessFunc has one
+// input, so the n-input sum is not a Processor.  Mix is a helper for a custom component that owns
+// n upstream buffers of equal length.
+type Mix struct {
+	p *C.pipe_hip_processor
+}
+
+func NewMix(inputs, bufferSize, channels int, o Options) (*Mix, error) {
+	cfg := o.config(bufferSize, channels, 1)
+	var p *C.pipe_hip_processor
+	if err := status(C.pipe_hip_mix_create(&cfg, C.int32_t(inputs), &p), "mix_create"); err != nil {
+		return nil, err
+	}
+	return &Mix{p: p}, nil
+}
+
+// Sum writes ((ins[0] + ins[1]) + ins[2]) ... into out; all slices hold frames*channels samples.
+func (m *Mix) Sum(ins [][]float64, frames int, out []float64) error {
+	ptrs := make([]unsafe.Pointer, len(ins))
+	pin := runtime.Pinner{}
+	defer pin.Unpin()
+	for i := range ins {
+		pin.Pin(&ins[i][0])
+		ptrs[i] = unsafe.Pointer(&ins[i][0])
+	}
+	st := C.pipe_hip_mix_process(m.p, (*unsafe.Pointer)(unsafe.Pointer(&ptrs[0])), C.int32_t(len(ins)),
+		C.int32_t(frames), unsafe.Pointer(&out[0]))
+	runtime.KeepAlive(ins)
+	runtime.KeepAlive(out)
+	return status(st, "mix_process")
+}
+
+func (m *Mix) Close() { C.pipe_hip_destroy(m.p) }

@@ -30,7 +30,23 @@ class PipeHipError(RuntimeError):
         super().__init__(f"{what}: {msg} (status {status}" + (f", hipError {hip})" if hip else ")"))
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libpipe_host.so")
+
 _lib = None
+_host_lib = None
+
+
+def host_lib():
+    """libpipe_host.so: the C++ mirror of the reference's host side (include/pipe_host.h), TEST
+    HARNESS -- it drives libpipe_hip.so through the C ABI the way the Go pipe would."""
+    global _host_lib
+    if _host_lib is None:
+        lib()  # the product library first: one HIP runtime, and libpipe_host.so links against it
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing: build it with __graft_entry__.build()")
+        _host_lib = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
+    return _host_lib
+
 
 
 def _share_torch_hip_runtime():
@@ -65,7 +81,7 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pipe_amd has no CPU fallback.")
     _share_torch_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     dp = C.POINTER(C.c_double)
     hp = C.POINTER(vp)
@@ -84,6 +100,7 @@ def lib():
         "pipe_hip_output_properties": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "pipe_hip_start": (C.c_int, [vp]),
         "pipe_hip_flush": (C.c_int, [vp]),
+        "pipe_hip_start_lines": (C.c_int, [vp, i32, i32]),
         "pipe_hip_destroy": (C.c_int, [vp]),
         "pipe_hip_process": (C.c_int, [vp, vp, i32, vp, i32, C.POINTER(i32)]),
         "pipe_hip_mix_process": (C.c_int, [vp, hp, i32, i32, vp]),

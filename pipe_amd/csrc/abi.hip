@@ -388,6 +388,18 @@ int pipe_hip_start(pipe_hip_processor *p)
     return PIPE_HIP_OK;
 }
 
+int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count)
+{
+    if (!p || first < 0 || count < 0 || first + count > p->cfg.lines)
+        return PIPE_HIP_EINVAL;
+    if (p->in_flight)
+        return PIPE_HIP_ESTATE;
+    PH_TRY(p->select_device());
+    PH_TRY(p->start_lines(first, count, p->stream));
+    PH_HIP(hipStreamSynchronize(p->stream));
+    return PIPE_HIP_OK;
+}
+
 int pipe_hip_flush(pipe_hip_processor *p)
 {
     if (!p)

@@ -448,6 +448,13 @@ public:
         PH_HIP(hipMemsetAsync(state_.p, 0, state_bytes_, s));
         return PIPE_HIP_OK;
     }
+    int start_lines(int first, int count, hipStream_t s) override
+    {
+        const size_t per = sizeof(double) * (size_t)cfg.channels * (size_t)S_ * 2u;
+        if (count > 0)
+            PH_HIP(hipMemsetAsync(static_cast<char *>(state_.p) + per * (size_t)first, 0, per * (size_t)count, s));
+        return PIPE_HIP_OK;
+    }
     int set_param(int32_t param, const double *values, int32_t count) override
     {
         if (param == PIPE_HIP_PARAM_EXACT && count == 1 && values) {

@@ -33,6 +33,12 @@ public:
             PH_TRY(st->start(s));
         return PIPE_HIP_OK;
     }
+    int start_lines(int first, int count, hipStream_t s) override
+    {
+        for (auto &st : stages)
+            PH_TRY(st->start_lines(first, count, s));
+        return PIPE_HIP_OK;
+    }
     int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
             hipStream_t s) override
     {

@@ -214,6 +214,15 @@ struct pipe_hip_processor {
 
     // zero per-Line state, asynchronously on `s`
     virtual int start(hipStream_t s) = 0;
+    // ... of Lines [first, first + count) only: a Line that joins a running batch handle
+    // (Pipe.AddLine, pipe.go:260-300) starts from silence without disturbing the others
+    virtual int start_lines(int first, int count, hipStream_t s)
+    {
+        (void)first;
+        (void)count;
+        (void)s;
+        return PIPE_HIP_EINVAL;
+    }
     // advance every Line by `frames` frames.  Device pointers, line-major.
     virtual int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
                     hipStream_t s) = 0;

@@ -412,6 +412,14 @@ public:
         return PIPE_HIP_OK;
     }
 
+    int start_lines(int first, int count, hipStream_t s) override
+    {
+        const size_t per = sizeof(double) * (size_t)H_ * (size_t)cfg.channels;
+        if (per && count > 0)
+            PH_HIP(hipMemsetAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)first, 0, per * (size_t)count, s));
+        return PIPE_HIP_OK;
+    }
+
     int set_param(int32_t param, const double *values, int32_t count) override
     {
         if (param == PIPE_HIP_PARAM_EXACT && count == 1 && values) {

@@ -188,8 +188,10 @@ public:
     }
     const std::shared_ptr<Handle> &handle() const { return h_; }
 
-    // every slot's StartFunc lands here (all of them run before the first pass: run.go:76-85)
-    error start() { return StatusError(pipe_hip_start(h_->get()), "start"); }
+    // a slot's StartFunc zeroes THAT Line's state only: the Lines of a group start together
+    // before the first pass (run.go:76-85), but a Line added to a running pipe (Pipe.AddLine) must
+    // not reset the others
+    error start(int slot) { return StatusError(pipe_hip_start_lines(h_->get(), slot, 1), "start"); }
 
     error ProcessLines(const std::vector<const signal::Floating *> &ins, const std::vector<signal::Floating *> &outs,
                        std::vector<int> *processed) override
@@ -258,7 +260,7 @@ std::vector<ProcessorAllocatorFunc> BatchedChain(std::vector<StageSpec> stages, 
             out->SignalProperties = input;  // a chain keeps rate and channels
             out->Batch = group;
             out->BatchSlot = slot;
-            out->StartFunc = [group](const Context &) -> error { return group->start(); };
+            out->StartFunc = [group, slot](const Context &) -> error { return group->start(slot); };
             out->FlushFunc = [group](const Context &) -> error {
                 return StatusError(pipe_hip_flush(group->handle()->get()), "flush");
             };

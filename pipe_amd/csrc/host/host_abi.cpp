@@ -1,4 +1,5 @@
 // C entry points of the host-side mirror (include/pipe_host.h).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -84,7 +85,9 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
     std::memset(err, 0, sizeof *err);
     std::memset(results, 0, sizeof(*results) * (size_t)n_lines);
     std::vector<std::unique_ptr<LineMocks>> mocks;
-    std::vector<Line> lines;
+    std::vector<Line> lines;           // bound at the start
+    std::vector<BatchedEdit> edits;    // RUN_BATCHED: Lines / Processors that arrive while the pipe runs
+    std::vector<int> route_of((size_t)n_lines, -1);
     std::vector<mut::Mutation> initializers_src;  // built after binding
     bool any_hip = false;
     hip::Options opt;
@@ -168,6 +171,7 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
             pm->ErrorOnFlush = inj(pd.err_on_flush);
             std::vector<double> params(pd.params ? pd.params : nullptr, pd.params ? pd.params + pd.n_params : nullptr);
             std::shared_ptr<hip::Handle> *hslot = &m->handles[(size_t)k];
+            const size_t before = l.Processors.size();
             switch (pd.kind) {
             case PIPE_HOST_PROC_MOCK:
                 l.Processors.push_back(pm->Allocator());
@@ -203,10 +207,42 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
             default:
                 return 1;
             }
+            if (mode == PIPE_HOST_MODE_RUN_BATCHED && pd.insert_before_pass > 0 && l.Processors.size() > before) {
+                // not part of the bound Line: inserted live at the position it would have had
+                BatchedEdit e;
+                e.kind = BatchedEdit::kInsertProcessor;
+                e.before_pass = pd.insert_before_pass;
+                e.route = i;  // fixed up below
+                e.pos = (int)before;
+                e.alloc = l.Processors.back();
+                l.Processors.pop_back();
+                edits.push_back(std::move(e));
+            }
             m->procs.push_back(std::move(pm));
         }
-        lines.push_back(std::move(l));
+        if (mode == PIPE_HOST_MODE_RUN_BATCHED && d.join_before_pass > 0) {
+            BatchedEdit e;
+            e.kind = BatchedEdit::kAddLine;
+            e.before_pass = d.join_before_pass;
+            e.line = std::move(l);
+            e.route = -1 - i;  // marks the description it came from
+            edits.push_back(std::move(e));
+        } else {
+            route_of[(size_t)i] = (int)lines.size();
+            lines.push_back(std::move(l));
+        }
         mocks.push_back(std::move(m));
+    }
+    {   // route indices: the Lines bound at the start in order, then the added ones in arrival order
+        std::stable_sort(edits.begin(), edits.end(),
+                         [](const BatchedEdit &a, const BatchedEdit &b) { return a.before_pass < b.before_pass; });
+        int next = (int)lines.size();
+        for (auto &e : edits)
+            if (e.kind == BatchedEdit::kAddLine)
+                route_of[(size_t)(-1 - e.route)] = next++;
+        for (auto &e : edits)
+            if (e.kind == BatchedEdit::kInsertProcessor)
+                e.route = route_of[(size_t)e.route];
     }
     if (any_hip)
         hip::UsePinnedPools();
@@ -219,7 +255,7 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
             if (r > 0)
                 for (auto &m : mocks)
                     m->source.Reset().Apply();
-            run_err = mode == PIPE_HOST_MODE_RUN ? Run(ctx, buffer_size, lines) : RunBatched(ctx, buffer_size, lines);
+            run_err = mode == PIPE_HOST_MODE_RUN ? Run(ctx, buffer_size, lines) : RunBatched(ctx, buffer_size, lines, nullptr, edits);
         }
     } else {
         std::unique_ptr<Pipe> p;

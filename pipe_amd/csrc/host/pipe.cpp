@@ -568,6 +568,70 @@ struct stageMajorExecutor final : executor {
         std::shared_ptr<lineExecutor> le;
     };
     std::vector<entry> lines;
+    // live edits: applied between passes, like the mutations of run.go:134-169
+    std::vector<BatchedEdit> edits;
+    int pass = 0, bufferSize = 0, nextRoute = 0;
+    mut::Context mctx;
+
+    // Pipe.AddLine for a sync Line joining this executor: bind, connect, start, append
+    // (pipe.go:260-300; multiLineExecutor.addRoute run.go:134-145)
+    error addLine(const Context &ctx, Line l)
+    {
+        l.Context = mctx;
+        std::shared_ptr<route> r;
+        if (error err = bindLine(l, bufferSize, &r))
+            return Wrap("error adding line", err);
+        r->connect(bufferSize);
+        auto le = makeLineExecutor(r, nullptr, nextRoute++);
+        if (error err = le->startHook(ctx))
+            return Wrap("line failed to start", err);
+        lines.push_back({r, le});
+        return nullptr;
+    }
+    // Pipe.InsertProcessor on a sync Line: allocate against the previous stage's properties,
+    // connect behind its out, hand the new out to the next component, start, splice
+    // (runtime.insertProcessor pipe.go:314-333; startSyncProcessor run.go:147-169)
+    error insertProcessor(const Context &ctx, int routeIdx, int pos, const ProcessorAllocatorFunc &alloc)
+    {
+        for (auto &l : lines) {
+            if (l.le->routeIdx != routeIdx)
+                continue;
+            route &r = *l.r;
+            if (pos < 0 || (size_t)pos > r.processors.size())
+                return NewError("failed to insert processor: position out of range");
+            const SignalProperties prevProps = pos == 0 ? r.source->SignalProperties : r.processors[(size_t)pos - 1]->SignalProperties;
+            const out_link prevOut = pos == 0 ? r.source->out : r.processors[(size_t)pos - 1]->out;
+            auto proc = std::make_shared<Processor>();
+            const mut::Context c = componentContext(r.context);
+            if (error err = alloc(c, bufferSize, prevProps, proc.get()))
+                return Wrap("failed to insert processor", err);
+            proc->Context = c;
+            proc->connect(bufferSize, fitting::New(fitting::Sync), prevOut);
+            if ((size_t)pos < r.processors.size())
+                r.processors[(size_t)pos]->in.insert(proc->out);
+            else
+                r.sink->in.insert(proc->out);
+            if (error err = proc->startHook(ctx))
+                return Wrap("error starting processor", err);
+            r.processors.insert(r.processors.begin() + pos, proc);
+            l.le->executors.insert(l.le->executors.begin() + pos + 1, proc);
+            l.le->started++;
+            return nullptr;
+        }
+        return NewError("failed to insert processor: no such line");
+    }
+    error applyEdits(const Context &ctx)
+    {
+        for (auto &e : edits) {
+            if (e.before_pass != pass)
+                continue;
+            if (error err = e.kind == BatchedEdit::kAddLine ? addLine(ctx, e.line)
+                                                            : insertProcessor(ctx, e.route, e.pos, e.alloc))
+                return err;
+        }
+        ++pass;
+        return nullptr;
+    }
 
     error flushHook(const Context &ctx) override
     {
@@ -626,6 +690,9 @@ struct stageMajorExecutor final : executor {
 
     error execute(const Context &ctx) override
     {
+        if (!edits.empty())
+            if (error err = applyEdits(ctx))
+                return err;
         for (size_t i = 0; i < lines.size();) {
             error err = lines[i].r->source->execute(ctx);
             if (!err) {
@@ -776,10 +843,15 @@ error Run(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun 
     return runSync(ctx, e, detail);
 }
 
-error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail)
+error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail,
+                 std::vector<BatchedEdit> edits)
 {
     stageMajorExecutor e;
     const mut::Context mctx = mut::Mutable();
+    e.edits = std::move(edits);
+    e.bufferSize = bufferSize;
+    e.mctx = mctx;
+    e.nextRoute = (int)lines.size();
     for (size_t i = 0; i < lines.size(); ++i) {
         lines[i].Context = mctx;
         std::shared_ptr<route> r;

@@ -241,7 +241,22 @@ error Run(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun 
 // order within the Line, same EOF/flush/error rules); what changes is the interleaving across
 // Lines, which lets Processors that share a BatchGroup advance with one device launch.
 // Processors without a group execute one by one as in Run.  
-error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail = nullptr);
+// Live edits of a running batched pipe (second half).  In the reference they are
+// mutations the executor applies between two passes: Pipe.AddLine -> multiLineExecutor.addRoute
+// (pipe.go:260-300, run.go:134-145), Pipe.InsertProcessor -> runtime.insertProcessor +
+// multiLineExecutor.startSyncProcessor (pipe.go:302-365, run.go:147-169).  Here an edit names the
+// pass it arrives before, which is what a mutation pushed at that moment amounts to.
+struct BatchedEdit {
+    enum Kind { kAddLine, kInsertProcessor } kind = kAddLine;
+    int before_pass = 0;            // 0: after the start hooks, before the first pass
+    ::pipe::Line line;              // kAddLine
+    int route = 0;                  // kInsertProcessor: index of the Line (initial Lines 0..n-1 in the order
+                                    // given, added Lines continue the count) ...
+    int pos = 0;                    // ... and the position of the new Processor in its chain
+    ProcessorAllocatorFunc alloc;   // kInsertProcessor
+};
+error RunBatched(const Context &ctx, int bufferSize, std::vector<Line> lines, ErrorRun *detail = nullptr,
+                 std::vector<BatchedEdit> edits = {});
 
 // pipe.New + Start + Wait: immutable Line context => one thread per component
 // connected by capacity-1 channels; mutable context => sync executor per context.

@@ -19,7 +19,8 @@ MODE_RUN, MODE_ASYNC, MODE_RUN_BATCHED = 0, 1, 2
 class _ProcDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("params", C.POINTER(C.c_double)), ("n_params", C.c_int32),
                 ("err_on_call", C.c_int32), ("err_on_start", C.c_int32), ("err_on_flush", C.c_int32),
-                ("err_on_make", C.c_int32), ("mutate_gain", C.c_int32), ("mutated_gain", C.c_double)]
+                ("err_on_make", C.c_int32), ("mutate_gain", C.c_int32), ("mutated_gain", C.c_double),
+                ("insert_before_pass", C.c_int32)]
 
 
 class _LineDesc(C.Structure):
@@ -30,7 +31,7 @@ class _LineDesc(C.Structure):
                 ("n_procs", C.c_int32), ("procs", _ProcDesc * MAX_PROCS),
                 ("sink_discard", C.c_int32), ("sink_err_on_call", C.c_int32),
                 ("sink_err_on_start", C.c_int32), ("sink_err_on_flush", C.c_int32),
-                ("sink_err_on_make", C.c_int32)]
+                ("sink_err_on_make", C.c_int32), ("join_before_pass", C.c_int32)]
 
 
 class _Counter(C.Structure):
@@ -57,6 +58,7 @@ class Proc:
     err_on_flush: bool = False
     err_on_make: bool = False
     mutate_gain: Optional[float] = None
+    insert_before_pass: int = 0   # MODE_RUN_BATCHED: > 0 = inserted live before that pass (Pipe.InsertProcessor)
 
 
 @dataclass
@@ -77,6 +79,7 @@ class Line:
     sink_err_on_start: bool = False
     sink_err_on_flush: bool = False
     sink_err_on_make: bool = False
+    join_before_pass: int = 0     # MODE_RUN_BATCHED: > 0 = added to the running pipe before that pass (Pipe.AddLine)
 
 
 @dataclass
@@ -114,7 +117,7 @@ def _cnt(c) -> Counter:
 
 
 def run(buffer_size: int, lines: Sequence[Line], mode: int = MODE_RUN, runs: int = 1, device: int = 0):
-    L = _lib.lib()
+    L = _lib.host_lib()
     fn = L.pipe_host_run
     fn.restype = C.c_int
     fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_LineDesc), C.POINTER(_LineResult),
@@ -144,9 +147,11 @@ def run(buffer_size: int, lines: Sequence[Line], mode: int = MODE_RUN, runs: int
             q.err_on_flush, q.err_on_make = int(p.err_on_flush), int(p.err_on_make)
             if p.mutate_gain is not None:
                 q.mutate_gain, q.mutated_gain = 1, float(p.mutate_gain)
+            q.insert_before_pass = int(p.insert_before_pass)
         d.sink_discard = int(l.discard)
         d.sink_err_on_call, d.sink_err_on_start = int(l.sink_err_on_call), int(l.sink_err_on_start)
         d.sink_err_on_flush, d.sink_err_on_make = int(l.sink_err_on_flush), int(l.sink_err_on_make)
+        d.join_before_pass = int(l.join_before_pass)
     res = (_LineResult * len(lines))()
     err = _Error()
     rc = fn(mode, buffer_size, len(lines), descs, res, C.byref(err), runs, device)

@@ -79,6 +79,10 @@ class Processor:
     def start(self):
         L.check(L.lib().pipe_hip_start(self._h), "start")
 
+    def start_lines(self, first: int, count: int = 1):
+        """StartFunc of some Lines of a batch handle only (a Line joining a running group)."""
+        L.check(L.lib().pipe_hip_start_lines(self._h, int(first), int(count)), "start_lines")
+
     def flush(self):
         L.check(L.lib().pipe_hip_flush(self._h), "flush")
 

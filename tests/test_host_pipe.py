@@ -246,3 +246,67 @@ def test_batched_chain_lines_equal_oracle_loop(runs):
         # the sink keeps the LAST run's samples: after a restart they are the same samples again,
         # i.e. StartFunc zeroed the device state of every slot
         assert np.array_equal(h.values, o.values)
+
+
+# ---------------------------------------------------------------- live edits of a running batched pipe
+def test_live_add_line_and_insert_processor_follow_the_reference_rules():
+    """Pipe.AddLine / Pipe.InsertProcessor on the stage-major executor: both are
+    mutations the executor applies BETWEEN two passes (multiLineExecutor.addRoute run.go:134-145,
+    startSyncProcessor run.go:147-169).  A Line that joins before pass k runs exactly as it would
+    alone; an inserted Processor sees the buffers from that pass on, is started when it is inserted
+    and flushed with the Line; nobody else notices."""
+    mk = lambda n, i, **kw: H.Line(limit=n, channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False, **kw)
+    lens = [7 * BUF + 77, 6 * BUF, 4 * BUF + 5]
+    lines = [
+        mk(lens[0], 0, procs=[H.Proc(H.PROC_MOCK), H.Proc(H.PROC_MOCK, insert_before_pass=2)]),
+        mk(lens[1], 1, procs=[H.Proc(H.PROC_MOCK, insert_before_pass=3), H.Proc(H.PROC_MOCK)]),
+        mk(lens[2], 2, procs=[H.Proc(H.PROC_MOCK)], join_before_pass=3),
+    ]
+    err, res = H.run(BUF, lines, H.MODE_RUN_BATCHED)
+    assert not err.failed, err.message
+    for i, n in enumerate(lens):
+        alone_err, alone = H.run(BUF, [mk(n, i, procs=[H.Proc(H.PROC_MOCK)])], H.MODE_RUN)
+        assert not alone_err.failed
+        assert np.array_equal(res[i].values, alone[0].values)          # mock Processors are copies
+        total = alone[0].sink.messages
+        assert (res[i].sink.messages, res[i].sink.samples) == (total, n)
+        assert res[i].source.started and res[i].source.flushed and res[i].sink.flushed
+    total0, total1 = -(-lens[0] // BUF), -(-lens[1] // BUF)
+    assert res[0].procs[0].messages == total0
+    assert res[0].procs[1].messages == total0 - 2                       # inserted before pass 2
+    assert res[1].procs[0].messages == total1 - 3 and res[1].procs[1].messages == total1
+    for p in (res[0].procs[1], res[1].procs[0]):
+        assert p.started and p.flushed
+    assert res[2].procs[0].messages == -(-lens[2] // BUF)               # the late Line, whole
+
+
+@pytest.mark.gpu
+def test_live_add_line_joins_a_running_batch_handle_and_gain_is_inserted_mid_run():
+    # Lines 0, 1 run a batched HIP chain (one device handle, slots 0..2); Line 2 joins before pass 4 and
+    # takes slot 2: its state starts from silence (pipe_hip_start_lines), the others keep theirs.
+    # A HIP gain is inserted behind Line 0's chain before pass 3: buffers 0..2 leave unscaled,
+    # the rest scaled.  Everything bit for bit against the oracle loop.
+    C_ = 2
+    taps = synth.fir_lowpass_taps(64)
+    sos = synth.biquad_rbj_lowpass()
+    lens = [8 * BUF + 100, 9 * BUF, 5 * BUF + 17]
+    chain = H.Proc(H.PROC_HIP_CHAIN, H.chain_params(taps, sos, 0.5))
+    hlines = [
+        H.Line(limit=lens[0], channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(40), discard=False,
+               procs=[chain, H.Proc(H.PROC_HIP_GAIN, [0.25], insert_before_pass=3)]),
+        H.Line(limit=lens[1], channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(41), discard=False, procs=[chain]),
+        H.Line(limit=lens[2], channels=C_, src_kind=H.SRC_SYNTH, seed=synth.line_seed(42), discard=False, procs=[chain],
+               join_before_pass=4),
+    ]
+    herr, hres = H.run(BUF, hlines, H.MODE_RUN_BATCHED)
+    assert not herr.failed, herr.message
+    for i, n in enumerate(lens):
+        ol = O.Line(limit=n, channels=C_, src_kind=O.SRC_SYNTH, seed=synth.line_seed(40 + i), discard=False,
+                    procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_BIQUAD, sos), O.Proc(O.PROC_GAIN, [0.5])])
+        _, ores = O.run_lines(BUF, [ol])
+        want = ores[0].values.copy()
+        if i == 0:
+            want[3 * BUF * C_:] *= 0.25     # exact: a power of two
+        assert hres[i].sink.samples == n
+        assert np.array_equal(hres[i].values, want), f"line {i}"
+    assert hres[0].procs[1].messages == -(-lens[0] // BUF) - 3 and hres[0].procs[1].started and hres[0].procs[1].flushed
