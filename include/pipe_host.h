@@ -86,6 +86,9 @@ typedef struct pipe_host_error {
 int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines, const pipe_host_line_desc *lines,
                   pipe_host_line_result *results, pipe_host_error *err, int32_t runs, int32_t device);
 void pipe_host_free_values(double *values);
+/* signal buffers created by every PoolAllocator of this process so far (PoolAllocator, pipe.go:490-492):
+ * a running pipe recycles its buffers, so the count does not depend on how long the Lines are */
+int64_t pipe_host_pool_buffers_created(void);
 
 #ifdef __cplusplus
 }

@@ -300,3 +300,4 @@ extern "C" int pipe_host_run(int32_t mode, int32_t buffer_size, int32_t n_lines,
 }
 
 extern "C" void pipe_host_free_values(double *values) { std::free(values); }
+extern "C" int64_t pipe_host_pool_buffers_created(void) { return pipe::signal::PoolBuffersCreated(); }

@@ -1,3 +1,4 @@
+#include <atomic>
 #include "signal.hpp"
 
 #include <algorithm>
@@ -93,6 +94,9 @@ Floating Allocator::Float64() const
     return f;
 }
 
+static std::atomic<int64_t> g_pool_buffers_created{0};
+int64_t PoolBuffersCreated() { return g_pool_buffers_created.load(std::memory_order_relaxed); }
+
 PoolAllocator::PoolAllocator(int channels, int length, int capacity)
     : Channels(channels), Length(length), Capacity(capacity)
 {
@@ -110,6 +114,7 @@ Floating PoolAllocator::Float64()
             free_.pop_back();
         } else {
             ++allocated_;
+            g_pool_buffers_created.fetch_add(1, std::memory_order_relaxed);
         }
     }
     if (!s)

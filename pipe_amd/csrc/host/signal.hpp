@@ -90,6 +90,8 @@ private:
 
 // signal.GetPoolAllocator(channels, length, capacity)                pipe.go:491
 std::shared_ptr<PoolAllocator> GetPoolAllocator(int channels, int length, int capacity);
+// buffers created by ALL pools of the process since it started: the steady state of a pipe adds none
+int64_t PoolBuffersCreated();
 
 // copies min(src.Len(), dst.Len()) samples; returns FRAMES copied     mock.go:151
 int FloatingAsFloating(const Floating &src, Floating &dst);

@@ -112,6 +112,14 @@ def chain_params(taps, coeffs, gain) -> np.ndarray:
     return np.concatenate([[t.size], t, [c.shape[0]], c.ravel(), [gain]])
 
 
+def pool_buffers_created() -> int:
+    """Signal buffers created by every PoolAllocator of this process so far."""
+    fn = _lib.host_lib().pipe_host_pool_buffers_created
+    fn.restype = C.c_int64
+    fn.argtypes = []
+    return int(fn())
+
+
 def _cnt(c) -> Counter:
     return Counter(int(c.messages), int(c.samples), bool(c.started), bool(c.flushed))
 

@@ -36,7 +36,7 @@ def _dptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def _order_after_torch(stream):
+def _order_after_torch(stream, device=None):
     """The handle's own stream is non-blocking: it does not order itself after work torch has
     queued on ITS stream (a .contiguous() copy of the input, a fill of the output).  With no
     explicit stream the wrapper therefore waits for torch's current stream before launching;
@@ -45,7 +45,7 @@ def _order_after_torch(stream):
         return
     import torch
     if torch.cuda.is_available():
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(device).synchronize()   # the HANDLE's device, not torch's current one
 
 
 def _devptr(t) -> int:
@@ -211,7 +211,7 @@ class Processor:
         need = self.lines * int(frames_per_line) * self.channels
         self._check_device_tensor(d_in, need)
         self._check_device_tensor(d_out, need)
-        _order_after_torch(stream)
+        _order_after_torch(stream, self.device)
         L.check(L.lib().pipe_hip_process_batch(self._h, _devptr(d_in), _devptr(d_out),
                                                int(frames_per_line), C.c_void_p(stream or None)),
                 "process_batch")
@@ -309,7 +309,7 @@ class Resampler(Processor):
 
     def resample_batch(self, d_in, in_frames: int, d_out, out_cap_frames: int, stream: int = 0) -> int:
         n = C.c_int64()
-        _order_after_torch(stream)
+        _order_after_torch(stream, self.device)
         L.check(L.lib().pipe_hip_resample_batch(self._h, _devptr(d_in), int(in_frames), _devptr(d_out),
                                                 int(out_cap_frames), C.byref(n),
                                                 C.c_void_p(stream or None)), "resample_batch")
@@ -341,7 +341,7 @@ class Mix(Processor):
         for t in list(d_ins) + [d_out]:
             self._check_device_tensor(t, need)
         ptrs = (C.c_void_p * len(d_ins))(*[_devptr(t) for t in d_ins])
-        _order_after_torch(stream)
+        _order_after_torch(stream, self.device)
         L.check(L.lib().pipe_hip_mix_batch(self._h, ptrs, len(d_ins), _devptr(d_out),
                                            int(frames_per_line), C.c_void_p(stream or None)),
                 "mix_batch")

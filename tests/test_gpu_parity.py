@@ -465,6 +465,48 @@ def test_argument_errors():
         assert e.value.status == EINVAL
 
 
+# ------------------------------------------------------------------ one process, several devices
+def test_handles_on_two_devices_in_one_process():
+    """pipe_hip.h "Threading": every entry point selects the handle's device itself, so one process
+    (a Go program with Lines on several GPUs) can interleave handles of different devices and call
+    them from different OS threads.  Needs >= 2 GPUs: skipped on the 1-GPU box, runs on the 8-GPU node."""
+    import threading
+    if P.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs")
+    F, C = 4096, 2
+    h = synth.fir_lowpass_taps(256)
+    xs = [sig(60 + d, 6 * F, C, np.float32) for d in range(2)]
+    want = [expect(O.Fir(h, C).process(x.astype(np.float64)), np.float32) for x in xs]
+    procs = [P.Fir(h, F, C, device=d) for d in range(2)]
+    for p in procs:
+        p.start()
+    # (1) interleaved from one thread: buffer k of device 0, then buffer k of device 1
+    got = [[], []]
+    for k in range(3):
+        for d in range(2):
+            got[d].append(procs[d].process(xs[d][k * F:(k + 1) * F]))
+    # (2) the remaining buffers from two threads at once
+    def drive(d):
+        for k in range(3, 6):
+            got[d].append(procs[d].process(xs[d][k * F:(k + 1) * F]))
+    ts = [threading.Thread(target=drive, args=(d,)) for d in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for d in range(2):
+        assert np.array_equal(np.concatenate(got[d]), want[d]), f"device {d}"
+    # (3) device-resident batch on device 1 while device 0 is torch's current device
+    torch.cuda.set_device(0)
+    d_in = torch.from_numpy(xs[1][None]).to("cuda:1")
+    d_out = torch.empty_like(d_in)
+    with P.Fir(h, 6 * F, C, device=1) as b:
+        b.start()
+        b.process_batch(d_in, d_out, 6 * F)
+        b.flush()
+    assert np.array_equal(d_out.cpu().numpy()[0], want[1])
+    for p in procs:
+        p.close()
+
+
 # ------------------------------------------------------------------ non-finite samples
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_exact_forms_treat_non_finite_samples_like_the_oracle(dtype):

@@ -310,3 +310,27 @@ def test_live_add_line_joins_a_running_batch_handle_and_gain_is_inserted_mid_run
         assert hres[i].sink.samples == n
         assert np.array_equal(hres[i].values, want), f"line {i}"
     assert hres[0].procs[1].messages == -(-lens[0] // BUF) - 3 and hres[0].procs[1].started and hres[0].procs[1].flushed
+
+
+# ---------------------------------------------------------------- the pools recycle: no allocation in the steady state
+@pytest.mark.parametrize("mode", [H.MODE_RUN, H.MODE_ASYNC, H.MODE_RUN_BATCHED])
+def test_pool_allocators_create_no_buffers_in_the_steady_state(mode):
+    """PoolAllocator (pipe.go:490-492; Source.execute pipe.go:394, Processor.execute :437 draw from it,
+    `defer m.Signal.Free` :426,:458 hand the buffer back): the number of buffers a pipe ever creates is
+    set by its topology -- a 100x longer stream creates exactly as many as a short one."""
+    def created(buffers):
+        mk = lambda i: H.Line(limit=buffers * BUF, channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i),
+                              procs=[H.Proc(H.PROC_MOCK), H.Proc(H.PROC_MOCK)])
+        before = H.pool_buffers_created()
+        err, res = H.run(BUF, [mk(0), mk(1)], mode)
+        assert not err.failed and res[0].sink.messages == buffers
+        return H.pool_buffers_created() - before
+    short, long_ = created(8), created(800)
+    if mode == H.MODE_ASYNC:
+        # one thread per stage: a pool's buffers are the one being filled, the one waiting in the fitting
+        # (capacity 1) and the one the next stage reads: at most 3 per pool, 3 pools per Line, 2 Lines --
+        # set by the pipeline's depth, not by the stream's length
+        assert short <= 18 and long_ <= 18
+    else:
+        assert long_ == short == 2 * 3   # one buffer per pool: the input is freed before the next pass
+
