@@ -95,7 +95,11 @@ func (b *Batch) Allocator(slot int) pipe.ProcessorAllocatorFunc {
 		}
 		return pipe.Processor{
 			SignalProperties: in, // a fixed-rate chain keeps rate and channels
-			StartFunc:        func(context.Context) error { return status(C.pipe_hip_start(b.p), "start") },
+			// only THIS Line's slot starts from silence: a Line added to a running pipe (pipe.go:260-300)
+			// must not reset the Lines that are already streaming through the same handle
+			StartFunc: func(context.Context) error {
+				return status(C.pipe_hip_start_lines(b.p, C.int32_t(slot), 1), "start_lines")
+			},
 			FlushFunc:        func(context.Context) error { return status(C.pipe_hip_flush(b.p), "flush") },
 			ProcessFunc: func(signal.Floating, signal.Floating) (int, error) {
 				return 0, errors.New("hip.Batch: run the Lines with pipe.RunBatched")
