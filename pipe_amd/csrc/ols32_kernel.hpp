@@ -162,8 +162,13 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned ta
 template <int S, bool GENERAL>
 __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb, const Args32 &a,
                                                const FuseArgs &fa, const FuseConst<S> &fc, int line, int tile, int pair,
-                                               bool valid, int l5, int half PH_FPROF_PARAMS)
+                                               bool valid, int l5_in, int half PH_FPROF_PARAMS)
 {
+    // The epilogue's per-lane table addresses are invariant over the unit loop; hoisted out of it
+    // they would sit in ~40 registers through the transform, which has none to give.  An opaque
+    // copy of the lane index keeps them inside.
+    int l5 = l5_in;
+    asm volatile("" : "+v"(l5));
     constexpr int N2 = 2 * S;
     constexpr int NV = 2 * N2;  // doubles per record: two channels x 2S states
     const int64_t len64 = a.frames - (int64_t)tile * a.L;
@@ -173,19 +178,9 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     const int64_t series = (int64_t)line * a.pairs + pair;
     unsigned long long *recs = fa.rec + (series * a.tiles_per_line) * (2 * 2 * NV);  // this series' records
 
-    // requested now, wanted later: the first scan matrix; for the forgetful form also this lane's
-    // power of M^L and -- if this lane stands for "tile -1" -- the stage's own state
+    // requested now, wanted later: the first scan matrix
     double m0[N2][N2];
     load_mat<S>(m0, fa.mats, kMatAk + 1);
-    double tj0[N2][N2], own[NV];
-    if constexpr (!GENERAL) {
-        load_mat<S>(tj0, fa.mats, kMatTj + l5);
-        const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
-        const bool mine = valid && tile - 1 - l5 == -1 && l5 < fc.D;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            own[j] = mine ? sp[j] : 0.0;
-    }
 
     // ---- 1. segment layout, 2. zero-state pass ----------------------------------------------
     // Channel 0's segment stays in registers; channel 1's stays in the plane (it is the last one
@@ -287,6 +282,19 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     };
     publish(0, Zr, Zi);  // A: the aggregate, before anything is waited for
     PH_FSTAMP(3);  // publish A
+
+    // for the forgetful form: this lane's power of M^L and -- if this lane stands for "tile -1" --
+    // the stage's own state; requested here (not at the top: 16 registers held through the scan
+    // were 16 too many), they arrive while the predecessors are polled
+    double tj0[N2][N2], own[NV];
+    if constexpr (!GENERAL) {
+        load_mat<S>(tj0, fa.mats, kMatTj + l5);
+        const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
+        const bool mine = valid && tile - 1 - l5 == -1 && l5 < fc.D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            own[j] = mine ? sp[j] : 0.0;
+    }
 
     double sr[N2], si[N2];  // start state of the tile
 #pragma unroll
@@ -646,7 +654,9 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             // The epilogue is chains of dependent fma and round trips, a few instructions each: they
             // go ahead of the other wave's dense transform on this SIMD, which loses nothing by it.
             __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_sched_barrier(0);  // the epilogue's early loads stay out of the transform's registers
             fused_epilogue<S, GENERAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half PH_FPROF_ARGS);
+            __builtin_amdgcn_sched_barrier(0);  // ... and the store addresses are not computed ahead of it
             __builtin_amdgcn_s_setprio(0);
         }
 
