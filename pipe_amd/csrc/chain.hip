@@ -29,12 +29,16 @@ public:
     }
     int start(hipStream_t s) override
     {
+        if (fused_)
+            fused_->drop_state();
         for (auto &st : stages)
             PH_TRY(st->start(s));
         return PIPE_HIP_OK;
     }
     int start_lines(int first, int count, hipStream_t s) override
     {
+        if (fused_)
+            PH_TRY(fused_->export_state(s));  // the other Lines keep their state
         for (auto &st : stages)
             PH_TRY(st->start_lines(first, count, s));
         return PIPE_HIP_OK;
@@ -65,6 +69,8 @@ public:
                 }
             }
         }
+        if (fused_)
+            PH_TRY(fused_->export_state(s));  // the staged form reads the biquad stage's own array
         PH_TRY(timer.begin(s));
         int hop = 0;
         for (size_t i = 0; i < ns; ++i) {

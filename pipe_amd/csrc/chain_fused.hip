@@ -96,13 +96,15 @@ void store_flat(double *dst, const Mat &m)
 // 32-position segment that holds that frame (seg_state); here one half-wave per (Line, channel)
 // series stages the segment's input window in LDS, computes the FIR output of its <= 32 frames
 // in the direct form (the oracle's own ordered sum, one frame per lane, taps as scalar operands)
-// and walks the recurrence over them.  Runs behind the fused kernel on the same stream, so it
-// writes the biquad stage's state array itself.
+// and walks the recurrence over them.  Runs behind the fused kernel on the same stream -- only when
+// the Line does not end on a segment boundary (frames % 32 != 0); otherwise the fused kernel has the
+// state itself -- and writes the series' state slot in its place.
 struct TailArgs {
     int64_t frames, line_stride;
     int C, N, H, HP, L, tiles_per_line, nseries;  // nseries = lines * C
     const double *seg_state;                       // [lines][pairs][2][2S]
-    double *state;                                 // [lines][C][2S]: the biquad stage's own
+    unsigned long long *own;                       // [lines][pairs][2 slots][...]: ols32_kernel.hpp
+    unsigned epoch;
 };
 constexpr int kTailSeries = 8;  // series (half-waves) per workgroup
 typedef const __attribute__((address_space(4))) double *tail_const_f64;
@@ -182,17 +184,53 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
     for (int c = 0; c <= jl; ++c)
         (void)ols::biquad_step<S>(__shfl(y, c, 32), st, fc);
     if (l5 == 0) {
-        double *dst = a.state + (int64_t)sid * N2;
+        constexpr int NV = 2 * N2;
+        unsigned long long *slot =
+            ols::own_write_slot<NV>(a.own + (int64_t)(line * (a.C / 2) + ch / 2) * (2 * 2 * NV), a.epoch);
 #pragma unroll
         for (int j = 0; j < N2; ++j)
-            dst[j] = st[j];
+            ols::own_store(slot + 2 * ((ch & 1) * N2 + j), a.epoch, st[j]);
     }
+}
+
+// The biquad stage's own state array <-> the state slots, when a chain changes between its staged
+// and its fused form (one thread per channel pair).
+template <int S>
+__global__ void chain_state_import_kernel(const double *__restrict__ state, unsigned long long *own, int nseries2,
+                                          unsigned epoch)
+{
+    constexpr int NV = 4 * S;
+    const int sid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (sid >= nseries2)
+        return;
+    unsigned long long *o = own + (int64_t)sid * (2 * 2 * NV);
+    for (int slot = 0; slot < 2; ++slot)  // equal tags: the reader takes slot 0, the writer slot 1
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            ols::own_store(o + slot * (2 * NV) + 2 * j, epoch, state[(int64_t)sid * NV + j]);
+}
+template <int S>
+__global__ void chain_state_export_kernel(double *__restrict__ state, const unsigned long long *own, int nseries2,
+                                          unsigned epoch)
+{
+    constexpr int NV = 4 * S;
+    const int sid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (sid >= nseries2)
+        return;
+    double pay[NV];
+    ols::own_read<NV>(own + (int64_t)sid * (2 * 2 * NV), epoch, pay);  // (epoch: one no launch has used)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        state[(int64_t)sid * NV + j] = pay[j];
 }
 
 }  // namespace
 
 struct Plan::Impl {
-    DevBuf rec, mats[2], seg_state, err, prof;
+    DevBuf rec, mats[2], seg_state, own, err, prof;
+    int own_series = 0;       // channel pairs the slots were sized for
+    bool in_slots = false;    // the cascade's state lives in the slots (else in the biquad stage's array)
+    double *bq_state = nullptr;
     int cur_mats = 0;
     AsyncUpload upload;  // pinned staging of the matrices
     std::vector<double> coeffs;
@@ -306,6 +344,22 @@ int Plan::poll_error(hipStream_t s)
     return PIPE_HIP_OK;
 }
 
+// the cascade's state back into the biquad stage's own array: before anything but the fused
+// kernel touches it
+int Plan::export_state(hipStream_t s)
+{
+    Impl &I = *impl_;
+    if (!I.in_slots)
+        return PIPE_HIP_OK;
+    hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                       I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
+    PH_HIP(hipGetLastError());
+    I.in_slots = false;
+    return PIPE_HIP_OK;
+}
+// the stage's own array has been reset (StartFunc): what the slots hold is void
+void Plan::drop_state() { impl_->in_slots = false; }
+
 template <int S, bool GENERAL>
 static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const double *hist, Args32 a, const FuseArgs &fa,
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
@@ -391,15 +445,34 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         PH_HIP(hipMemsetAsync(I.rec.p, 0, sizeof(unsigned long long) * need, s));
         I.rec_granules = need;
     }
-    if (++I.epoch == 0) {  // 2^32 launches: tags would repeat
+    if (I.epoch >= 0xFFFFFFF0u) {  // 2^32 launches: tags would repeat
+        PH_TRY(export_state(s));
         PH_HIP(hipMemsetAsync(I.rec.p, 0, sizeof(unsigned long long) * I.rec_granules, s));
-        I.epoch = 1;
+        I.epoch = 0;
     }
+    // the cascade's state: in the tagged slots while the chain stays fused (ols32_kernel.hpp)
+    const int nseries2 = lines * a.pairs;
+    if (I.own_series != nseries2) {
+        PH_TRY(export_state(s));
+        PH_HIP(hipStreamSynchronize(s));
+        PH_TRY(I.own.alloc(sizeof(unsigned long long) * (size_t)nseries2 * (2 * 2 * NV)));
+        I.own_series = nseries2;
+    }
+    I.bq_state = bq.state;
+    if (!I.in_slots) {
+        ++I.epoch;
+        hipLaunchKernelGGL(chain_state_import_kernel<1>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
+                           I.epoch);
+        PH_HIP(hipGetLastError());
+        I.in_slots = true;
+    }
+    ++I.epoch;
     FuseArgs fa{};
     fa.k0 = a.HP / 32;
     fa.epoch = I.epoch;
     fa.rec = static_cast<unsigned long long *>(I.rec.p);
-    fa.state = bq.state;
+    fa.own = static_cast<unsigned long long *>(I.own.p);
     const size_t seg_bytes = sizeof(double) * (size_t)lines * a.pairs * NV;
     if (I.seg_state.bytes < seg_bytes)
         PH_TRY(I.seg_state.alloc(seg_bytes));
@@ -429,7 +502,9 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
         PH_TRY((launch<1, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     }
-    if (!std::getenv("PIPE_HIP_CHAIN_NO_TAIL")) {  // (debug switch) the state after every Line's last frame
+    // the state after every Line's last frame: the fused kernel's own work when the Line ends on a
+    // segment boundary (PIPE_HIP_CHAIN_NO_TAIL: debug switch)
+    if (frames % 32 != 0 && !std::getenv("PIPE_HIP_CHAIN_NO_TAIL")) {
         TailArgs ta{};
         ta.frames = frames;
         ta.line_stride = a.line_stride;
@@ -441,7 +516,8 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.tiles_per_line = a.tiles_per_line;
         ta.nseries = lines * channels;
         ta.seg_state = static_cast<const double *>(I.seg_state.p);
-        ta.state = bq.state;
+        ta.own = static_cast<unsigned long long *>(I.own.p);
+        ta.epoch = I.epoch;
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
         hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,

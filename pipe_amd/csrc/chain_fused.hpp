@@ -31,6 +31,13 @@ public:
             KernelTimer *timer, const char **kernel_name);
     // EHIP if a launch since the last poll gave up waiting for a predecessor tile
     int poll_error(hipStream_t s);
+    // While a chain stays fused the cascade's state lives in the plan (two tagged slots per channel
+    // pair: the last tile of a launch writes it, the first tiles of the next read it, no kernel in
+    // between).  export_state() moves it back into the biquad stage's own array -- before the
+    // staged chain, a windowed run or a partial restart touches that -- and drop_state() forgets it
+    // (the stage's array was just reset).
+    int export_state(hipStream_t s);
+    void drop_state();
 
 private:
     int prepare(const double *coeffs, int S, int ntaps, hipStream_t s);

@@ -76,7 +76,8 @@ struct FuseArgs {
     int k0;                      // HP / 32: the lane (segment) of a tile's first output; HP % 32 == 0
     unsigned epoch;              // tag of this launch's records (never 0)
     unsigned long long *rec;     // [series][tile][A | P][2 NV] 8-byte {tag, half a double} granules
-    const double *state;         // [lines][C][S][2]: the biquad stage's own state, read at a Line's first tile
+    unsigned long long *own;     // [series][2 slots][2 NV] granules: the cascade's state between launches
+                                 // (own_read / own_write below)
     double *seg_state;           // [series][2 channels][2S]: start state of the segment that holds the
                                  // Line's last frame (for chain_tail_kernel)
     const double *mats;          // the matrices above
@@ -143,6 +144,44 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned tag, unsigned v)
 {
     __hip_atomic_store(p, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the cascade's state between launches -------------------------------------------------------
+// The state after a Line's last frame is written by the wave that runs the Line's LAST tile and read
+// by the waves of its FIRST tiles -- of the same launch, in no particular order.  Two slots per
+// series, every granule tagged with the epoch of the launch that wrote it: the writer takes the
+// slot with the OLDER tag, the reader the NEWER one that is not this launch's.  Neither ever waits.
+//   slot layout: [2 NV] granules = NV doubles (channel 0's 2S states, channel 1's), low word first
+template <int NV>
+__device__ __forceinline__ int own_newer_slot(const unsigned long long *o, unsigned epoch)
+{
+    const unsigned a0 = epoch - (unsigned)(granule_load(o) >> 32);
+    const unsigned a1 = epoch - (unsigned)(granule_load(o + 2 * NV) >> 32);
+    // age 0: being written by this launch
+    return a0 == 0u ? 1 : (a1 == 0u ? 0 : (a1 < a0 ? 1 : 0));
+}
+template <int NV>
+__device__ __forceinline__ void own_read(const unsigned long long *o, unsigned epoch, double (&pay)[NV])
+{
+    const unsigned long long *r = o + own_newer_slot<NV>(o, epoch) * (2 * NV);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const unsigned long long g0 = granule_load(r + 2 * j), g1 = granule_load(r + 2 * j + 1);
+        pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
+    }
+}
+// (channel threads of chain_tail_kernel write half a slot each: the slot choice depends only on
+// tags of earlier launches, or on "already this launch's")
+template <int NV>
+__device__ __forceinline__ unsigned long long *own_write_slot(unsigned long long *o, unsigned epoch)
+{
+    return o + (1 - own_newer_slot<NV>(o, epoch)) * (2 * NV);
+}
+__device__ __forceinline__ void own_store(unsigned long long *dst, unsigned epoch, double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    granule_store(dst, epoch, (unsigned)b);
+    granule_store(dst + 1, epoch, (unsigned)(b >> 32));
 }
 
 // One tile (FIR output in lo/hi, natural layout, re/im = the pair's two channels) through the
@@ -289,11 +328,12 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     double tj0[N2][N2], own[NV];
     if constexpr (!GENERAL) {
         load_mat<S>(tj0, fa.mats, kMatTj + l5);
-        const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
         const bool mine = valid && tile - 1 - l5 == -1 && l5 < fc.D;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            own[j] = mine ? sp[j] : 0.0;
+            own[j] = 0.0;
+        if (mine)
+            own_read<NV>(fa.own + series * (2 * 2 * NV), fa.epoch, own);
     }
 
     double sr[N2], si[N2];  // start state of the tile
@@ -394,11 +434,12 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                     if (l5 <= jlim && (st == 1 || l5 == jp) && (ask || u == -1)) {
                         double wr[N2], wi[N2];
                         if (u == -1) {  // the series starts here: the biquad stage's own state
-                            const double *sp = fa.state + ((int64_t)line * a.C + 2 * pair) * N2;
+                            double pay[NV];
+                            own_read<NV>(fa.own + series * (2 * 2 * NV), fa.epoch, pay);
     #pragma unroll
                             for (int j = 0; j < N2; ++j) {
-                                wr[j] = sp[j];
-                                wi[j] = sp[N2 + j];
+                                wr[j] = pay[j];
+                                wi[j] = pay[N2 + j];
                             }
                         } else {
                             const unsigned long long *rr = r + (st == 2 ? 2 * NV : 0);
@@ -487,11 +528,15 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         affine<S>(str, er, pk, sr);
         affine<S>(sti, ei, pk, si);
     }
-    // The Line's last tile: the state after the Line's LAST frame is the biquad stage's state for
-    // the next call.  That frame sits in the middle of a segment (step jl of lane kl), so this
-    // kernel only hands out the segment's true start state; chain_tail_kernel (chain_fused.hip)
-    // walks the <= 32 frames from there.  No second shape of the loop below, nothing inside it.
-    if (valid && last_tile && l5 == ((a.HP + len - 1) >> 5)) {
+    // The Line's last tile: the state after the Line's LAST frame is the cascade's state for the
+    // next call.  When the Line ends where a segment ends (frames % 32 == 0: every power-of-two
+    // buffer size) that is lane kl's state after the loop below, and it goes to the series' state
+    // slot from here.  Otherwise the frame sits in the middle of a segment (step jl of lane kl):
+    // the kernel hands out the segment's true start state and chain_tail_kernel (chain_fused.hip)
+    // walks the <= 32 frames from there.  No second shape of the loop, nothing inside it.
+    const bool ends_here = valid && last_tile && l5 == ((a.HP + len - 1) >> 5);
+    const bool on_boundary = ((a.HP + len) & 31) == 0;
+    if (ends_here && !on_boundary) {
         double *sp = fa.seg_state + series * NV;
 #pragma unroll
         for (int j = 0; j < N2; ++j) {
@@ -510,6 +555,14 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         for (int c = 0; c < 32; ++c) {
             xr[c] = biquad_step<S>(xr[c], str, fc) * fc.gain;
             xi[c] = biquad_step<S>(xi[c], sti, fc) * fc.gain;
+        }
+        if (ends_here && on_boundary) {
+            unsigned long long *dst = own_write_slot<NV>(fa.own + series * (2 * 2 * NV), fa.epoch);
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                own_store(dst + 2 * j, fa.epoch, str[j]);
+                own_store(dst + 2 * (N2 + j), fa.epoch, sti[j]);
+            }
         }
         PH_FSTAMP(6);  // pass 3
         // ---- back to natural layout (channel 1 first: the plane is still its) ------------------

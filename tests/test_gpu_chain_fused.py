@@ -126,3 +126,47 @@ def test_full_config3_shape_spot_lines(monkeypatch):
     for l in (0, 1, 170, 171, 255, 340, 511):
         d = ulps(got[l], oracle_chain(taps, LOWPASS, g, x[l]))
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
+
+
+@pytest.mark.parametrize("q", [LOWPASS, DC_BLOCK], ids=["forgetful", "general"])
+def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
+    """Between two fused launches the cascade's state lives in the plan's tagged slots (written by the
+    launch's last tiles when the buffer ends on a segment boundary, frames % 32 == 0, by the tail
+    kernel otherwise); the staged form and a partial restart use the biquad stage's own array.  A
+    stream that keeps changing between all of them must still be the oracle's stream."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, ntaps, g = 6, 4, 256, 0.5
+    # (frames, exact): exact = PIPE_HIP_PARAM_EXACT on for this call -> the staged bit-exact chain
+    plan = [(4096, False), (4096, False), (1000, False), (4096, True), (4096, False), (37, True), (2048, False),
+            (4096 + 5, False), (4096, False)]
+    total = sum(n for n, _ in plan)
+    restart_before, restarted = 5, (1, 2)   # Lines 1..2 start again from silence before call 5
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    x = np.random.default_rng(11).uniform(-1, 1, size=(lines, total, C)).astype(np.float32)
+    kw = dict(dtype=np.float32, lines=lines, max_batch=1)
+    with P.Chain([P.Fir(taps, 8192, C, **kw), P.Biquad(q, 8192, C, **kw), P.Gain(g, 8192, C, **kw)]) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        outs, names, pos = [], [], 0
+        for k, (n, exact) in enumerate(plan):
+            if k == restart_before:
+                p.start_lines(restarted[0], restarted[1] - restarted[0] + 1)
+            p._set_param(3, [1.0 if exact else 0.0])
+            xin = d_in[:, pos:pos + n, :].contiguous()
+            y = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, y, n)
+            torch.cuda.synchronize()
+            names.append(p.kernel_name())
+            outs.append(y)
+            pos += n
+        p.flush()
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    assert ["chain_fused" in nm for nm in names] == [not e for _, e in plan], names
+    cut = sum(n for n, _ in plan[:restart_before])
+    for l in range(lines):
+        if restarted[0] <= l <= restarted[1]:
+            want = np.concatenate([oracle_chain(taps, q, g, x[l, :cut]), oracle_chain(taps, q, g, x[l, cut:])])
+        else:
+            want = oracle_chain(taps, q, g, x[l])
+        d = ulps(got[l], want)
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at frame {np.argmax(d) // C}"
