@@ -346,12 +346,21 @@ public:
         const bool reg_taps = (T_ == 8 || T_ == 12 || T_ == 16 || T_ == 24 || T_ == 32) && up_ <= kThreads &&
                               !std::getenv("PIPE_HIP_RESAMPLE_LDS_TAPS");
         const int q = reg_taps ? up_ * (kThreads / up_) : kThreads;
-        const int tile_out = reg_taps ? q * (kOutTile / q) : kOutTile;
-        // staged window of a tile: frames read by tile_out outputs, plus history, plus slack
-        const int win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
-        int plane = win + 1;
-        plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
-        const size_t lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
+        // outputs per tile: kOutTile, halved until table + planes fit the 64 KB a workgroup may take
+        // (wide Lines: 8 channels at 160 x 24 take tiles of 480 and stay on this kernel: 95 us where
+        // the gather kernel takes 213) -- never below one output per computing lane
+        int tile_out = 0, win = 0, plane = 0;
+        size_t lds = 0;
+        for (int cap = kOutTile; cap >= q; cap /= 2) {
+            tile_out = reg_taps ? q * (cap / q) : cap;
+            // staged window of a tile: frames read by tile_out outputs, plus history, plus slack
+            win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
+            plane = win + 1;
+            plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
+            lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
+            if (lds <= 64 * 1024)
+                break;
+        }
         const bool tiled = lds <= 64 * 1024 && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
         if (total > 0 && tiled) {
             TiledArgs t{};
