@@ -151,7 +151,7 @@ def config3():
     kw = dict(dtype=np.float32, lines=L, max_batch=1)
     with P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.7071067811865476, F, C, **kw)]) as p:
         p.start()
-        batch(3, f"{L} Lines x 8 ch x 4096 frames f32, FIR-256 + biquad + gain chain (f64 intermediates)",
+        batch(3, f"{L} Lines x 8 ch x 4096 frames f32, FIR-256 + biquad + gain chain (one fused kernel)",
               p, d_in, d_out, F, n, reps=10)
         pcie_inclusive(3, f"PCIe-inclusive: pipe_hip_process, the same chain from host buffers ({L} Lines x 4096x8 f32)",
                        p, L, F, C, reps=8)
