@@ -210,11 +210,16 @@ def main():
     achieved_gbs = n_elems * bps / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     # float64 operations the launched kernel form executes per scalar sample:
     #   direct form      : 2 * taps (ordered fma chain, bit-exact)
-    #   overlap-save FFT : ~1060 DP instructions (~210 of them fma) per lane per 1024-point item
+    #   overlap-save FFT : per lane and unit (two 1024-point items, 64 lanes) 760 add + 162 mul + 948 fma
+    #                      = 2818 flops as issued (scripts/count_dp.sh; an fma counted as two);
+    #   fused chain      : + two biquad passes over the item (9 and 10 flops per sample) and the scan
     is_fused = "chain_fused" in kname
     is_ols = "ols" in kname or is_fused
-    if is_ols:
-        flop_per_sample = (1058 + 209) * 64 / ((1025 - N) * 2.0)
+    if is_fused:
+        tile = 1024 - (N - 1 + 31) // 32 * 32
+        flop_per_sample = 2818 * 64 / (2 * tile * 2.0) + 19.0 * 1024 / tile + 1.0
+    elif is_ols:
+        flop_per_sample = 2818 * 64 / (2 * (1025 - N) * 2.0)
     else:
         flop_per_sample = 2.0 * N
     flops = flop_per_sample * n_elems
