@@ -360,19 +360,20 @@ int Plan::export_state(hipStream_t s)
 // the stage's own array has been reset (StartFunc): what the slots hold is void
 void Plan::drop_state() { impl_->in_slots = false; }
 
-template <int S, bool GENERAL>
+template <int S, bool GENERAL, bool LOCAL>
 static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const double *hist, Args32 a, const FuseArgs &fa,
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
 {
-    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL>;
-    const size_t lds =
-        sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) + sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32;
+    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
+    const size_t lds = sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) +
+                       sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
+                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing : 0);
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     // every workgroup of the grid must be resident (tiles wait for their predecessors): one
     // 512-thread workgroup per CU, never more
     const int64_t resident = P.cus;
-    const int64_t wanted = (a.nunits + kWaves32 - 1) / kWaves32;
+    const int64_t wanted = LOCAL ? a.lines : (a.nunits + kWaves32 - 1) / kWaves32;
     const unsigned grid = (unsigned)(wanted < resident ? wanted : resident);
     const int64_t stride = (int64_t)grid * kWaves32;
     a.d_slot = (int)(stride % a.upl);
@@ -493,14 +494,26 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     if (S != 1)
         return PIPE_HIP_EINVAL;  // kMaxFusedSections
     I.c1.gain = has_gain ? gain : 1.0;
+    // Block-local look-back (ols32_kernel.hpp): at least as many Lines as CUs -- a workgroup per CU,
+    // whole Lines per workgroup, balanced to within one Line -- and predecessors within the record
+    // ring's reach.  PIPE_HIP_CHAIN_LOCAL=0 switches it off (tests, A/B).
+    const char *local_env = std::getenv("PIPE_HIP_CHAIN_LOCAL");
+    const bool local = !general && !(local_env && local_env[0] == '0') && lines >= P.cus &&
+                       (int64_t)I.D * a.pairs <= ols::kLocalRing - 32 &&
+                       (lines % P.cus == 0 || lines >= 8 * P.cus);
+    a.local = local ? 1 : 0;
     if (general) {
         I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
         *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
-        PH_TRY((launch<1, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        PH_TRY((launch<1, true, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+    } else if (local) {
+        I.c1.D = I.D;
+        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,local>";
+        PH_TRY((launch<1, false, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     } else {
         I.c1.D = I.D;
         *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
-        PH_TRY((launch<1, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        PH_TRY((launch<1, false, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     }
     // the state after every Line's last frame: the fused kernel's own work when the Line ends on a
     // segment boundary (PIPE_HIP_CHAIN_NO_TAIL: debug switch)

@@ -48,6 +48,7 @@ struct Args32 {
     int L;                // valid outputs per tile = 1024 - HP
     int pairs, lines, tiles_per_line;
     int ipl, upl;         // items per Line (tiles x pairs); units (item pairs) per Line
+    int local;            // fused chain: every Line's tiles run in ONE workgroup, records in LDS (below)
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
     double *hist_new;
@@ -184,6 +185,22 @@ __device__ __forceinline__ void own_store(unsigned long long *dst, unsigned epoc
     granule_store(dst + 1, epoch, (unsigned)(b >> 32));
 }
 
+// ---- block-local look-back --------------------------------------------------------------------
+// A hand-off between workgroups costs 2-3 us under load (the poll waits in the consumer CU's memory
+// queue).  When there are at least as many Lines as workgroups, a workgroup takes whole Lines, so a
+// tile's predecessors run in the same workgroup -- in the same round of 16 items or the one before --
+// and the aggregates pass through a ring of records in LDS instead: kLocalRing records of
+// {NV doubles, tag}, slot = item index % kLocalRing, tag = item index / kLocalRing + 1 (the ring is
+// zeroed at kernel start).  A workgroup barrier after every round bounds the drift between waves to
+// one round, so a slot is never overwritten while it can still be read (predecessors reach back at
+// most kLocalRing - 32 items: the host checks D * pairs against that).
+constexpr int kLocalRing = 64;
+template <int NV>
+struct LocalRec {
+    double v[NV];
+    unsigned long long tag;
+};
+
 // One tile (FIR output in lo/hi, natural layout, re/im = the pair's two channels) through the
 // cascade, in place.  Per half-wave = per item:
 //   1. transpose to SEGMENT layout through the item's plane: lane k owns window positions
@@ -198,11 +215,13 @@ __device__ __forceinline__ void own_store(unsigned long long *dst, unsigned epoc
 //      from its true start state, applies the gain, and the tile goes back to natural layout.
 // Float64 values differ from the ordered recurrence only through the start states (O(1e-16)
 // relative, reassociation of steps 3-4), exactly like the time-segmented biquad.
-template <int S, bool GENERAL>
+template <int S, bool GENERAL, bool LOCAL>
 __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb, const Args32 &a,
                                                const FuseArgs &fa, const FuseConst<S> &fc, int line, int tile, int pair,
-                                               bool valid, int l5_in, int half PH_FPROF_PARAMS)
+                                               bool valid, int l5_in, int half, LocalRec<4 * S> *ring,
+                                               int gi PH_FPROF_PARAMS)
 {
+    static_assert(!(GENERAL && LOCAL), "the block-local records serve the forgetful form");
     // The epilogue's per-lane table addresses are invariant over the unit loop; hoisted out of it
     // they would sit in ~40 registers through the transform, which has none to give.  An opaque
     // copy of the lane index keeps them inside.
@@ -319,7 +338,21 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
             }
         }
     };
-    publish(0, Zr, Zi);  // A: the aggregate, before anything is waited for
+    if constexpr (LOCAL) {
+        if (l5 == 31 && valid && !last_tile) {
+            LocalRec<NV> *r = ring + (gi & (kLocalRing - 1));
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                r->v[j] = Zr[j];
+                r->v[N2 + j] = Zi[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&r->tag, (unsigned long long)(gi / kLocalRing + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        publish(0, Zr, Zi);  // A: the aggregate, before anything is waited for
+    }
     PH_FSTAMP(3);  // publish A
 
     // for the forgetful form: this lane's power of M^L and -- if this lane stands for "tile -1" --
@@ -360,7 +393,31 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         }
         bool ready = !(need && u >= 0);
         unsigned spins = 0;
-        while (!__all(ready)) {
+        if constexpr (LOCAL) {
+            const int gp = gi - (l5 + 1) * a.pairs;  // predecessor t - 1 - l5 of this pair
+            const LocalRec<NV> *r = ring + (gp & (kLocalRing - 1));
+            const unsigned long long want = (unsigned long long)(gp / kLocalRing + 1);
+            while (!__all(ready)) {
+                if (!ready) {
+                    if (__hip_atomic_load(&r->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                        for (int j = 0; j < N2; ++j) {
+                            wr[j] = r->v[j];
+                            wi[j] = r->v[N2 + j];
+                        }
+                        ready = true;
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 24)) {
+                            *fa.err = 1;
+                            ready = true;
+                        }
+                    }
+                }
+            }
+        }
+        while (!LOCAL && !__all(ready)) {
             if (!ready) {
                 const unsigned long long *r = recs + (int64_t)u * (2 * 2 * NV);
                 double pay[NV];
@@ -588,7 +645,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
 
 // S = 0: the FIR alone.  S = 1, 2: the FIR's tile goes through an S-section biquad cascade and a
 // gain before it is stored (chain_fused.hip; fa / fc are then the epilogue's arguments).
-template <typename TIn, typename TOut, int S = 0, bool GENERAL = false>
+template <typename TIn, typename TOut, int S = 0, bool GENERAL = false, bool LOCAL = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
 fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
                  const double2 *__restrict__ tw_g, const double2 *__restrict__ hperm_g, const Args32 a,
@@ -598,6 +655,12 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     double2 *hspec = reinterpret_cast<double2 *>(smem_raw);       // H[0..512] (+ pad)
     double2 *tws = hspec + kHalf32 + 1;                              // W1024^(k n), k = 1..31, n = 0..31
     double *planes = reinterpret_cast<double *>(tws + 31 * 32);   // [waves][2][kPlane32]
+    LocalRec<4 * (S > 0 ? S : 1)> *ring =
+        reinterpret_cast<LocalRec<4 * (S > 0 ? S : 1)> *>(planes + (size_t)kWaves32 * 2 * kPlane32);  // LOCAL only
+    if constexpr (LOCAL) {
+        for (int i = threadIdx.x; i < kLocalRing; i += kWaves32 * 64)
+            ring[i].tag = 0;
+    }
 
     fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
@@ -622,10 +685,18 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     // consecutive units go to consecutive blocks of the same XCD (block b runs on XCD b % 8):
     // neighbouring tiles share their overlap through that XCD's L2
     const int xb = nb % 8 == 0 ? ((int)blockIdx.x % 8) * (nb / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
-    const int64_t wave_global = (int64_t)wave_u * nb + xb;
-    const int64_t wave_stride = (int64_t)nb * kWaves32;
+    // LOCAL: this workgroup runs Lines blockIdx, blockIdx + nb, ... whole; its units are those Lines'
+    // units one after the other, eight (one per wave) to a round
+    const int my_lines = LOCAL ? (a.lines - (int)blockIdx.x + nb - 1) / nb : 0;
+    const int64_t my_units = (int64_t)my_lines * a.upl;
+    const int64_t wave_global = LOCAL ? (int64_t)wave_u : (int64_t)wave_u * nb + xb;
+    const int64_t wave_stride = LOCAL ? (int64_t)kWaves32 : (int64_t)nb * kWaves32;
+    const int64_t unit_end = LOCAL ? (my_units + kWaves32 - 1) / kWaves32 * kWaves32 : a.nunits;  // LOCAL: whole rounds
     int line = 0, slot = 0;
-    if (wave_global < a.nunits) {
+    if (LOCAL) {
+        line = (int)blockIdx.x + __builtin_amdgcn_readfirstlane((int)(wave_global / a.upl)) * nb;
+        slot = __builtin_amdgcn_readfirstlane((int)(wave_global % a.upl));
+    } else if (wave_global < a.nunits) {
         line = __builtin_amdgcn_readfirstlane((int)(wave_global / a.upl));
         slot = __builtin_amdgcn_readfirstlane((int)(wave_global % a.upl));
     }
@@ -638,7 +709,11 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     unsigned long long fprof_acc[kFuseProfPhases] = {};
     unsigned long long fprof_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (int64_t unit = wave_global; unit < a.nunits; unit += wave_stride) {
+    for (int64_t unit = wave_global; unit < unit_end; unit += wave_stride) {
+        if (LOCAL && unit >= my_units) {  // a wave without a unit in the workgroup's last round
+            __syncthreads();
+            continue;
+        }
         // ---- the unit's two items: item0 = 2 slot (half 0), item0 + 1 (half 1) -----------------
         const int item0 = 2 * slot;
         const int tile0 = __builtin_amdgcn_readfirstlane(item0 / a.pairs);
@@ -694,12 +769,18 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         }
         // the next unit's coordinates (uniform)
         const int cur_line = line;
-        slot += a.d_slot;
-        if (slot >= a.upl) {
-            slot -= a.upl;
-            ++line;
+        if constexpr (LOCAL) {
+            const int64_t nu = unit + wave_stride;
+            line = (int)blockIdx.x + __builtin_amdgcn_readfirstlane((int)(nu / a.upl)) * nb;
+            slot = __builtin_amdgcn_readfirstlane((int)(nu % a.upl));
+        } else {
+            slot += a.d_slot;
+            if (slot >= a.upl) {
+                slot -= a.upl;
+                ++line;
+            }
+            line += a.d_line;
         }
-        line += a.d_line;
 
         ols32_transform(lo, hi, pa, pb, twl, hlo, hhi);
         if constexpr (S > 0) {
@@ -708,7 +789,9 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             // go ahead of the other wave's dense transform on this SIMD, which loses nothing by it.
             __builtin_amdgcn_s_setprio(3);
             __builtin_amdgcn_sched_barrier(0);  // the epilogue's early loads stay out of the transform's registers
-            fused_epilogue<S, GENERAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half PH_FPROF_ARGS);
+            // (LOCAL: item index in the workgroup's list = two per unit, Lines padded to whole units)
+            fused_epilogue<S, GENERAL, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
+                                              (int)(2 * unit) + half PH_FPROF_ARGS);
             __builtin_amdgcn_sched_barrier(0);  // ... and the store addresses are not computed ahead of it
             __builtin_amdgcn_s_setprio(0);
         }
@@ -731,6 +814,8 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         if constexpr (S > 0)
             PH_FSTAMP(9);  // stores
 #endif
+        if constexpr (LOCAL)
+            __syncthreads();  // a round ends: no wave runs further ahead than the record ring reaches back
     }
 #ifdef PH_FUSE_PROF
     if constexpr (S > 0) {

@@ -170,3 +170,28 @@ def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
             want = oracle_chain(taps, q, g, x[l])
         d = ulps(got[l], want)
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at frame {np.argmax(d) // C}"
+
+
+@pytest.mark.parametrize("lines,C,calls", [
+    (256, 2, [4096, 2500, 4096]),    # one pair: a tile's predecessor is the other half of its own wave
+    (512, 6, [3000]),                # three pairs, four tiles: 12 items per Line
+    (256, 6, [2000, 2000]),          # three pairs, three tiles: 9 items, the Line is padded to whole units
+    (2100, 2, [1600]),               # Lines not a multiple of the workgroups: 9 Lines on some, 8 on others
+])
+def test_block_local_look_back_equals_the_global_one(lines, C, calls, monkeypatch):
+    """With at least as many Lines as CUs a workgroup runs whole Lines and the tile aggregates pass
+    through a record ring in LDS instead of global memory (ols32_kernel.hpp, kLocalRing).  Same sums in
+    the same order: bit for bit the result of the global look-back, and the oracle's within 1 ulp."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    frames = sum(calls)
+    taps = synth.fir_lowpass_taps(256, f32_rounded=True)
+    x = np.random.default_rng(lines + C).uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
+    got, names = run_chain(taps, LOWPASS, 0.5, x, calls)
+    assert all(n.endswith(",local>") for n in names), names
+    monkeypatch.setenv("PIPE_HIP_CHAIN_LOCAL", "0")
+    ref, names = run_chain(taps, LOWPASS, 0.5, x, calls)
+    assert all("chain_fused" in n and "local" not in n for n in names), names
+    assert np.array_equal(got, ref)
+    for l in (0, 1, lines // 2, lines - 1):
+        d = ulps(got[l], oracle_chain(taps, LOWPASS, 0.5, x[l]))
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
