@@ -367,7 +367,7 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
     auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
     const size_t lds = sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) +
                        sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
-                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing : 0);
+                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing + 4 * sizeof(unsigned) : 0);
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     // every workgroup of the grid must be resident (tiles wait for their predecessors): one
@@ -499,7 +499,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // ring's reach.  PIPE_HIP_CHAIN_LOCAL=0 switches it off (tests, A/B).
     const char *local_env = std::getenv("PIPE_HIP_CHAIN_LOCAL");
     const bool local = !general && !(local_env && local_env[0] == '0') && lines >= P.cus &&
-                       (int64_t)I.D * a.pairs <= ols::kLocalRing - 32 &&
+                       (int64_t)I.D * a.pairs <= ols::kLocalReach &&
                        (lines % P.cus == 0 || lines >= 8 * P.cus);
     a.local = local ? 1 : 0;
     if (general) {

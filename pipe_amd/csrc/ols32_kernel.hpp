@@ -191,10 +191,13 @@ __device__ __forceinline__ void own_store(unsigned long long *dst, unsigned epoc
 // tile's predecessors run in the same workgroup -- in the same round of 16 items or the one before --
 // and the aggregates pass through a ring of records in LDS instead: kLocalRing records of
 // {NV doubles, tag}, slot = item index % kLocalRing, tag = item index / kLocalRing + 1 (the ring is
-// zeroed at kernel start).  A workgroup barrier after every round bounds the drift between waves to
-// one round, so a slot is never overwritten while it can still be read (predecessors reach back at
-// most kLocalRing - 32 items: the host checks D * pairs against that).
+// zeroed at kernel start).  A wave starts round r only when every wave has finished round r - 2
+// (four counters in LDS, one per round mod 4): waves drift apart by at most one round, so the record
+// of item g -- read by items up to g + D * pairs <= g + 32, i.e. in rounds <= round(g) + 2 -- is
+// overwritten (by item g + 64, in round(g) + 4) only after its last reader's round has ended.  A
+// plain barrier per round would do, and costs a fifth of the kernel in waves waiting for the slowest.
 constexpr int kLocalRing = 64;
+constexpr int kLocalReach = 32;  // the host checks D * pairs against this
 template <int NV>
 struct LocalRec {
     double v[NV];
@@ -657,9 +660,12 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     double *planes = reinterpret_cast<double *>(tws + 31 * 32);   // [waves][2][kPlane32]
     LocalRec<4 * (S > 0 ? S : 1)> *ring =
         reinterpret_cast<LocalRec<4 * (S > 0 ? S : 1)> *>(planes + (size_t)kWaves32 * 2 * kPlane32);  // LOCAL only
+    unsigned *round_done = reinterpret_cast<unsigned *>(ring + kLocalRing);  // [4], LOCAL only
     if constexpr (LOCAL) {
         for (int i = threadIdx.x; i < kLocalRing; i += kWaves32 * 64)
             ring[i].tag = 0;
+        if (threadIdx.x < 4)
+            round_done[threadIdx.x] = 0;
     }
 
     fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
@@ -709,10 +715,27 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
     unsigned long long fprof_acc[kFuseProfPhases] = {};
     unsigned long long fprof_last = __builtin_amdgcn_s_memtime();
 #endif
+    int round = 0;
+    auto end_round = [&]() {
+        if constexpr (LOCAL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_fetch_add(&round_done[round & 3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++round;
+        }
+    };
     for (int64_t unit = wave_global; unit < unit_end; unit += wave_stride) {
-        if (LOCAL && unit >= my_units) {  // a wave without a unit in the workgroup's last round
-            __syncthreads();
-            continue;
+        if constexpr (LOCAL) {
+            if (round >= 2) {  // everybody is through round - 2 (its count: 8 per pass over the four counters)
+                const unsigned want = (unsigned)kWaves32 * (unsigned)((round - 2) / 4 + 1);
+                while (__hip_atomic_load(&round_done[(round - 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+                    __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            if (unit >= my_units) {  // a wave without a unit in the workgroup's last round
+                end_round();
+                continue;
+            }
         }
         // ---- the unit's two items: item0 = 2 slot (half 0), item0 + 1 (half 1) -----------------
         const int item0 = 2 * slot;
@@ -814,8 +837,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         if constexpr (S > 0)
             PH_FSTAMP(9);  // stores
 #endif
-        if constexpr (LOCAL)
-            __syncthreads();  // a round ends: no wave runs further ahead than the record ring reaches back
+        end_round();
     }
 #ifdef PH_FUSE_PROF
     if constexpr (S > 0) {
