@@ -177,6 +177,8 @@ def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
     (512, 6, [3000]),                # three pairs, four tiles: 12 items per Line
     (256, 6, [2000, 2000]),          # three pairs, three tiles: 9 items, the Line is padded to whole units
     (2100, 2, [1600]),               # Lines not a multiple of the workgroups: 9 Lines on some, 8 on others
+    (768, 4, [15000]),               # three Lines of 40 items per workgroup: 8 rounds, the round counters wrap
+    (256, 16, [1700]),               # eight pairs: a predecessor is 8 items (half a round) back
 ])
 def test_block_local_look_back_equals_the_global_one(lines, C, calls, monkeypatch):
     """With at least as many Lines as CUs a workgroup runs whole Lines and the tile aggregates pass
