@@ -130,7 +130,9 @@ int pipe_hip_start(pipe_hip_processor *p);
  * the new Line's components between two passes, run.go:134-145) begins from silence while the
  * other Lines keep their state.  Fixed-rate processors; PIPE_HIP_EINVAL otherwise. */
 int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count);
-/* FlushFunc (pipe.go:84-86; run.go:54-62): drain the handle's stream. */
+/* FlushFunc (pipe.go:84-86; run.go:54-62): drain everything the handle has queued -- on its own
+ * stream and on the caller's stream the last device-resident call named (StartFunc drains the same
+ * way before it resets the state). */
 int pipe_hip_flush(pipe_hip_processor *p);
 /* Releases device and pinned memory.  (Go has no destructor hook; the shim ties
  * it to FlushFunc of the last run or a finalizer.) */

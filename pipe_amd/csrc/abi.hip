@@ -379,10 +379,8 @@ int pipe_hip_start(pipe_hip_processor *p)
     if (!p)
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
-    if (p->in_flight) {  // a restarted pipe drops whatever was in flight
-        PH_HIP(hipStreamSynchronize(p->stream));
-        p->in_flight = 0;
-    }
+    PH_TRY(p->drain());  // a restarted pipe drops whatever was in flight, on whichever stream
+    p->in_flight = 0;
     PH_TRY(p->start(p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
     return PIPE_HIP_OK;
@@ -395,6 +393,7 @@ int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count)
     if (p->in_flight)
         return PIPE_HIP_ESTATE;
     PH_TRY(p->select_device());
+    PH_TRY(p->drain());
     PH_TRY(p->start_lines(first, count, p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
     return PIPE_HIP_OK;
@@ -405,7 +404,7 @@ int pipe_hip_flush(pipe_hip_processor *p)
     if (!p)
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
-    PH_HIP(hipStreamSynchronize(p->stream));
+    PH_TRY(p->drain());
     p->in_flight = 0;
     return p->poll_error();
 }
@@ -694,6 +693,7 @@ int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    p->batch_stream = s;
     return p->run(d_in, p->cfg.dtype, d_out, p->cfg.dtype, frames_per_line, s);
 }
 
@@ -706,6 +706,7 @@ int pipe_hip_resample_batch(pipe_hip_processor *p, const void *d_in, int64_t in_
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    p->batch_stream = s;
     return p->run_var(d_in, p->cfg.dtype, in_frames_per_line, d_out, p->cfg.dtype, out_cap_frames,
                       out_frames, s);
 }
@@ -717,6 +718,7 @@ int pipe_hip_mix_batch(pipe_hip_processor *p, const void *const *d_ins, int32_t 
         return PIPE_HIP_EINVAL;
     PH_TRY(p->select_device());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    p->batch_stream = s;
     return mix_run(p, d_ins, n_inputs, d_out, frames_per_line, s);
 }
 

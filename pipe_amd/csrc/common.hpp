@@ -159,6 +159,15 @@ private:
 struct pipe_hip_processor {
     pipe_hip_config cfg{};
     hipStream_t stream = nullptr;  // the handle's own stream
+    hipStream_t batch_stream = nullptr;  // a caller's stream the last device-resident call went to (if not `stream`)
+    // StartFunc / FlushFunc order themselves after everything the handle has queued anywhere
+    int drain() const
+    {
+        if (batch_stream && batch_stream != stream)
+            PH_HIP(hipStreamSynchronize(batch_stream));
+        PH_HIP(hipStreamSynchronize(stream));
+        return PIPE_HIP_OK;
+    }
     pipehip::KernelTimer timer;
     const char *last_kernel = "";
 

@@ -36,16 +36,34 @@ def _dptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def _order_after_torch(stream, device=None):
-    """The handle's own stream is non-blocking: it does not order itself after work torch has
-    queued on ITS stream (a .contiguous() copy of the input, a fill of the output).  With no
-    explicit stream the wrapper therefore waits for torch's current stream before launching;
-    callers that care about overlap (bench.py) pass torch's stream and skip this."""
-    if stream:
-        return
-    import torch
-    if torch.cuda.is_available():
-        torch.cuda.current_stream(device).synchronize()   # the HANDLE's device, not torch's current one
+class _TorchOrder:
+    """Runs a device-resident call in torch's stream order.  The tensors come from torch: their memory
+    is handed out and taken back in the order of TORCH's current stream, so the kernels that touch
+    them must sit in that order too -- on the handle's own (non-blocking) stream a kernel could still
+    be reading an input that torch has already given to the next allocation (seen: the fill of a
+    later output landing in an earlier call's input).  torch's default stream cannot be named through
+    the C ABI (its handle is NULL = "the handle's own stream"), so every Processor owns a side stream:
+    it waits for torch's current stream, the call is launched on it, torch's current stream waits
+    for it.  No host synchronisation anywhere."""
+
+    def __init__(self, proc, stream):
+        self.proc, self.explicit = proc, stream
+
+    def __enter__(self) -> int:
+        if self.explicit:
+            return self.explicit
+        import torch
+        p = self.proc
+        if getattr(p, "_side", None) is None:
+            p._side = torch.cuda.Stream(device=p.device)
+        self.cur = torch.cuda.current_stream(p.device)
+        p._side.wait_stream(self.cur)
+        return p._side.cuda_stream
+
+    def __exit__(self, *exc):
+        if not self.explicit:
+            self.cur.wait_stream(self.proc._side)
+        return False
 
 
 def _devptr(t) -> int:
@@ -211,10 +229,10 @@ class Processor:
         need = self.lines * int(frames_per_line) * self.channels
         self._check_device_tensor(d_in, need)
         self._check_device_tensor(d_out, need)
-        _order_after_torch(stream, self.device)
-        L.check(L.lib().pipe_hip_process_batch(self._h, _devptr(d_in), _devptr(d_out),
-                                               int(frames_per_line), C.c_void_p(stream or None)),
-                "process_batch")
+        with _TorchOrder(self, stream) as st:
+            L.check(L.lib().pipe_hip_process_batch(self._h, _devptr(d_in), _devptr(d_out),
+                                                   int(frames_per_line), C.c_void_p(st)),
+                    "process_batch")
 
     def _check_device_tensor(self, t, need: int):
         import torch
@@ -309,10 +327,10 @@ class Resampler(Processor):
 
     def resample_batch(self, d_in, in_frames: int, d_out, out_cap_frames: int, stream: int = 0) -> int:
         n = C.c_int64()
-        _order_after_torch(stream, self.device)
-        L.check(L.lib().pipe_hip_resample_batch(self._h, _devptr(d_in), int(in_frames), _devptr(d_out),
-                                                int(out_cap_frames), C.byref(n),
-                                                C.c_void_p(stream or None)), "resample_batch")
+        with _TorchOrder(self, stream) as st:
+            L.check(L.lib().pipe_hip_resample_batch(self._h, _devptr(d_in), int(in_frames), _devptr(d_out),
+                                                    int(out_cap_frames), C.byref(n), C.c_void_p(st)),
+                    "resample_batch")
         return n.value
 
 
@@ -341,10 +359,10 @@ class Mix(Processor):
         for t in list(d_ins) + [d_out]:
             self._check_device_tensor(t, need)
         ptrs = (C.c_void_p * len(d_ins))(*[_devptr(t) for t in d_ins])
-        _order_after_torch(stream, self.device)
-        L.check(L.lib().pipe_hip_mix_batch(self._h, ptrs, len(d_ins), _devptr(d_out),
-                                           int(frames_per_line), C.c_void_p(stream or None)),
-                "mix_batch")
+        with _TorchOrder(self, stream) as st:
+            L.check(L.lib().pipe_hip_mix_batch(self._h, ptrs, len(d_ins), _devptr(d_out),
+                                               int(frames_per_line), C.c_void_p(st)),
+                    "mix_batch")
 
 
 class Chain(Processor):
