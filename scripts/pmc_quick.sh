@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_q -o pmc -- "$@" > $OUT/cmd.out 2> $OUT/cmd.err
+timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --pmc $CNT -d $OUT/pmc_q -o pmc -- "$@" > $OUT/cmd.out 2> $OUT/cmd.err  # (a counter set rocprofv3 cannot schedule aborts and then hangs in its finalizer)
 cd $REPO
 python - "$OUT" <<'PY'
 import glob, os, sqlite3, sys, collections
