@@ -160,7 +160,11 @@ def main():
     for l, gl in enumerate(my_lines):
         P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl))
     torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
+    # The timed launches go to ONE stream named explicitly (torch's default stream has the NULL handle,
+    # which the C ABI reads as "the handle's own stream" and the Python harness then brackets with
+    # cross-stream waits: ~30 us of dependency latency per step that is the harness's, not the path's).
+    bench_stream = torch.cuda.Stream()
+    stream = bench_stream.cuda_stream
 
     def timed(p, steps, warmup, d_i, d_o, fpl, barrier=False):
         """(elapsed s, kernel ms total, launches, kernel name) of `steps` passes after `warmup`."""

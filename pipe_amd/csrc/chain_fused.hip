@@ -110,7 +110,7 @@ constexpr int kTailSeries = 8;  // series (half-waves) per workgroup
 typedef const __attribute__((address_space(4))) double *tail_const_f64;
 template <int S>
 __global__ void __launch_bounds__(32 * kTailSeries)
-chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ hist_base,
+chain_tail_kernel(const float *__restrict__ in_base, const float *__restrict__ hist_base,
                   const double *__restrict__ taps, const TailArgs a, const FuseConst<S> fc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
@@ -128,7 +128,7 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
     const int64_t f0 = t0 + 32 * kl - a.HP;  // first frame of the segment
     if (live) {
         const float *__restrict__ in = in_base + (int64_t)line * a.line_stride + ch;
-        const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
+        const float *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
         // all loads of a lane first, then the LDS stores: one memory round trip, not one per trip
         constexpr int kMaxTrips = (32 + 511 + 31) / 32;  // taps <= 512
         double v[kMaxTrips];
@@ -142,7 +142,7 @@ chain_tail_kernel(const float *__restrict__ in_base, const double *__restrict__ 
                     if (g < a.frames)
                         v[t] = (double)in[g * a.C];
                 } else if (g >= -(int64_t)a.H) {
-                    v[t] = hist[(g + a.H) * a.C];
+                    v[t] = (double)hist[(g + a.H) * a.C];
                 }
             }
         }
@@ -361,7 +361,7 @@ int Plan::export_state(hipStream_t s)
 void Plan::drop_state() { impl_->in_slots = false; }
 
 template <int S, bool GENERAL, bool LOCAL>
-static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const double *hist, Args32 a, const FuseArgs &fa,
+static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const void *hist, Args32 a, const FuseArgs &fa,
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
 {
     auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
@@ -382,7 +382,7 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
     if (timer)
         PH_TRY(timer->pair(&ev_a, &ev_b));
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const float *>(d_in),
-                          static_cast<float *>(d_out), hist, static_cast<const double2 *>(P.tw32.p),
+                          static_cast<float *>(d_out), static_cast<const float *>(hist), static_cast<const double2 *>(P.tw32.p),
                           static_cast<const double2 *>(P.hperm[P.cur].p), a, fa, fc);
     PH_HIP(hipGetLastError());
 #ifdef PH_FUSE_PROF
@@ -534,7 +534,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
         hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                           static_cast<const float *>(d_in), fir.hist, fir.taps, ta, I.c1);
+                           static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c1);
         PH_HIP(hipGetLastError());
     }
     return PIPE_HIP_OK;

@@ -268,8 +268,8 @@ struct pipe_hip_processor {
     // A FIR stage with an overlap-save plan / a biquad stage hand out what the fused kernel
     // needs; everything else answers false and the chain runs its stages one after the other.
     struct FirFuseView {
-        const double *hist;    // current history of all Lines
-        double *hist_new;      // the half the launch writes
+        const void *hist;      // current history of all Lines (float32 elements: the stream's type)
+        void *hist_new;        // the half the launch writes
         const void *plan;      // ols::Plan::Impl
         const double *taps;    // float64 taps on the device (the direct form's copy)
         int ntaps;

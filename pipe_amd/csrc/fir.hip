@@ -66,7 +66,7 @@ struct FirArgs {
     int out_off;          // byte offset of the wave-private output slabs in LDS
     int out_slab;         // elements per slab (padded)
     int taps_off;         // byte offset of the LDS copy of the taps
-    double *hist_new;     // the other half of the history double buffer (written by this launch)
+    void *hist_new;       // the other half of the history double buffer (written by this launch), TIn elements
 };
 
 // Taps are wave-uniform and immutable during a launch: reading them through the
@@ -123,14 +123,14 @@ __device__ __forceinline__ TileCoord decode_tile(const FirArgs &a, int id)
 template <int R, typename TIn, typename TOut>
 __global__ void __launch_bounds__(kThreads)
 fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
-                  const double *__restrict__ hist_base, const double *__restrict__ taps_base,
+                  const TIn *__restrict__ hist_base, const double *__restrict__ taps_base,
                   const FirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *xs = reinterpret_cast<double *>(smem_raw);
     constexpr int kStep = R > 1 ? R + 1 : 1;
 
-    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
+    fir_history_carry(in_base, hist_base, static_cast<TIn *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
 
     // staging map: lane -> (column tx = channel, row ty = frame) by shifts
     const int tx = threadIdx.x & ((1 << a.cx_log) - 1);
@@ -197,7 +197,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         const bool ok = tx < t.cg;
         const TIn *__restrict__ src =
             in_base + (int64_t)t.line * a.line_stride + t.c0 + (ok ? tx : 0);
-        const double *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
+        const TIn *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
         for (int fb0 = ty; fb0 < nfr; fb0 += 8 * FY) {
             TIn v[8];
 #pragma unroll
@@ -216,7 +216,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                     if (g >= 0)
                         w = g <= last ? loaded : 0.0;
                     else if (g >= -(int64_t)a.H)
-                        w = hist[(g + a.H) * a.C + t.c0 + tx];
+                        w = (double)hist[(g + a.H) * a.C + t.c0 + tx];
                     xs[tx * a.plane + pad_index<R>(f)] = w;
                 }
             }
@@ -409,12 +409,14 @@ public:
     {
         if (hist_bytes_)
             PH_HIP(hipMemsetAsync(hist_[cur_hist_].p, 0, hist_bytes_, s));
+        hist_dtype_ = -1;  // all zeros: the next call's sample type becomes the history's
         return PIPE_HIP_OK;
     }
 
     int start_lines(int first, int count, hipStream_t s) override
     {
-        const size_t per = sizeof(double) * (size_t)H_ * (size_t)cfg.channels;
+        // (no call yet since StartFunc: everything is zero already, in either layout)
+        const size_t per = hist_elem() * (size_t)H_ * (size_t)cfg.channels;
         if (per && count > 0)
             PH_HIP(hipMemsetAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)first, 0, per * (size_t)count, s));
         return PIPE_HIP_OK;
@@ -454,8 +456,12 @@ public:
         // a window of Lines (pipe_hip_process_lines with ragged lengths): the per-Line history
         // slices of exactly those Lines
         const int nl = active_lines();
-        const size_t hoff = (size_t)win_first * (size_t)H_ * (size_t)cfg.channels;
-        const double *hist = static_cast<const double *>(hist_[cur_hist_].p) + hoff;
+        // the history holds the stream's own sample type (fir_hist.hpp); a stage sees one type for life
+        if (hist_dtype_ >= 0 && hist_dtype_ != in_dtype)
+            return PIPE_HIP_EINVAL;
+        hist_dtype_ = in_dtype;
+        const size_t hoff = hist_elem() * (size_t)win_first * (size_t)H_ * (size_t)cfg.channels;  // bytes
+        const void *hist = static_cast<const char *>(hist_[cur_hist_].p) + hoff;
         // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
@@ -500,7 +506,10 @@ public:
     {
         if (!ols_ || windowed())
             return false;
-        v->hist = static_cast<const double *>(hist_[cur_hist_].p);
+        if (hist_dtype_ >= 0 && hist_dtype_ != PIPE_HIP_F32)
+            return false;  // (the fused kernel reads a float32 stream)
+        hist_dtype_ = PIPE_HIP_F32;
+        v->hist = hist_[cur_hist_].p;
         v->hist_new = hist_next();
         v->plan = &ols_->impl();
         v->taps = static_cast<const double *>(taps_[cur_taps_].p);
@@ -526,7 +535,8 @@ private:
 
     // new history = last N-1 frames of (old history ++ this call's input)
     // the launch just queued wrote the other half of the history double buffer
-    double *hist_next() const { return static_cast<double *>(hist_[cur_hist_ ^ 1].p); }
+    char *hist_next() const { return static_cast<char *>(hist_[cur_hist_ ^ 1].p); }
+    size_t hist_elem() const { return hist_dtype_ == PIPE_HIP_F32 ? sizeof(float) : sizeof(double); }
     int flip_history(hipStream_t s)
     {
         if (H_ <= 0)
@@ -534,7 +544,7 @@ private:
         if (windowed()) {
             // only the window's Lines were advanced: bring their new history back into the
             // current half instead of flipping the halves of every Line
-            const size_t per = sizeof(double) * (size_t)H_ * (size_t)cfg.channels;
+            const size_t per = hist_elem() * (size_t)H_ * (size_t)cfg.channels;
             PH_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)win_first,
                                   static_cast<const char *>(hist_[cur_hist_ ^ 1].p) + per * (size_t)win_first,
                                   per * (size_t)win_count, hipMemcpyDeviceToDevice, s));
@@ -620,7 +630,7 @@ private:
 
     template <int R>
     int launch_r(int in_dtype, int out_dtype, const Geometry &g, const void *d_in, void *d_out,
-                 const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
+                 const void *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
 #define PH_FIR_LAUNCH(TI, TO, NAME)                                                                  \
     do {                                                                                             \
@@ -632,7 +642,8 @@ private:
         hipEvent_t ev_a = nullptr, ev_b = nullptr;                                                   \
         PH_TRY(timer.pair(&ev_a, &ev_b));                                                            \
         hipExtLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, ev_a, ev_b, 0,                    \
-                              static_cast<const TI *>(d_in), static_cast<TO *>(d_out), hist, taps, a); \
+                              static_cast<const TI *>(d_in), static_cast<TO *>(d_out),                 \
+                              static_cast<const TI *>(hist), taps, a);                                 \
         last_kernel = NAME;                                                                          \
     } while (0)
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
@@ -667,7 +678,7 @@ private:
     }
 
     int launch(const Geometry &g, int in_dtype, int out_dtype, const void *d_in, void *d_out,
-               const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
+               const void *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
         switch (g.R) {
         case 16: return launch_r<16>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
@@ -688,6 +699,7 @@ private:
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;
     int cur_taps_ = 0, cur_hist_ = 0;
+    int hist_dtype_ = -1;  // sample type of the history's elements (-1: all zeros, not fixed yet)
     bool exact_ = std::getenv("PIPE_HIP_FIR_EXACT") != nullptr;
     std::unique_ptr<ols::Plan> ols_;
 };

@@ -51,7 +51,7 @@ struct Args32 {
     int local;            // fused chain: every Line's tiles run in ONE workgroup, records in LDS (below)
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
-    double *hist_new;
+    void *hist_new;       // TIn elements
 };
 
 // ---- the biquad + gain epilogue of the fused chain (chain_fused.hip) ---------------------------
@@ -650,7 +650,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
 // gain before it is stored (chain_fused.hip; fa / fc are then the epilogue's arguments).
 template <typename TIn, typename TOut, int S = 0, bool GENERAL = false, bool LOCAL = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
-fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
+fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const TIn *__restrict__ hist_base,
                  const double2 *__restrict__ tw_g, const double2 *__restrict__ hperm_g, const Args32 a,
                  const FuseArgs fa, const FuseConst<(S > 0 ? S : 1)> fc)
 {
@@ -668,7 +668,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             round_done[threadIdx.x] = 0;
     }
 
-    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
+    fir_history_carry(in_base, hist_base, static_cast<TIn *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
         hspec[i] = hperm_g[i];
     for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
@@ -769,7 +769,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         } else {
             // a Line's first tile: its head is the history
             const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-            const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+            const TIn *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
             const int64_t fr0 = (int64_t)tile * a.L - a.HP;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
@@ -783,8 +783,8 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
                         }
                     } else if (g >= -(int64_t)a.H) {  // (frames further back only reach positions
                                                       //  without output when HP > H)
-                        re = hist[(g + a.H) * a.C + c0];
-                        im = hist[(g + a.H) * a.C + c0 + 1];
+                        re = (double)hist[(g + a.H) * a.C + c0];
+                        im = (double)hist[(g + a.H) * a.C + c0 + 1];
                     }
                 }
                 PH_NAT(r) = cd{re, im};

@@ -16,6 +16,8 @@ from pipe_amd import host as H  # noqa: E402
 from pipe_amd import processors as P  # noqa: E402
 from pipe_amd import synth  # noqa: E402
 
+torch.cuda.set_stream(torch.cuda.Stream())  # device-resident calls launch directly on this stream (processors._TorchOrder)
+
 
 def emit(**kw):
     print(json.dumps(kw), flush=True)

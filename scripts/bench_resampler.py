@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pipe_amd import processors as P, synth  # noqa: E402
 
+torch.cuda.set_stream(torch.cuda.Stream())  # device-resident calls launch directly on this stream (processors._TorchOrder)
+
 for up, down, C in ((160, 147, 2), (147, 160, 2), (160, 147, 8), (2, 1, 2)):
     F, T, K = 4096, 24, 1024
     proto = synth.resampler_proto(up, down, T)
