@@ -56,11 +56,13 @@ public:
             BiquadFuseView bv{};
             double g = 1.0;
             const bool has_gain = ns == 3 && gain_value(stages[2].get(), &g);
-            if (stages[0]->fuse_view_fir(&fv) && stages[1]->fuse_view_biquad(&bv) && fv.relaxed && bv.relaxed &&
+            if (stages[0]->fuse_view_fir(&fv, s, false) && stages[1]->fuse_view_biquad(&bv) && fv.relaxed && bv.relaxed &&
                 bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
                 const int64_t L = 1024 - (fv.ntaps - 1 + 31) / 32 * 32;
                 const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
                 if (items >= fv.min_items) {
+                    if (!stages[0]->fuse_view_fir(&fv, s, true))  // (history into the fused kernel's layout)
+                        return PIPE_HIP_EHIP;
                     if (!fused_)
                         fused_.reset(new fused::Plan());
                     PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, frames, cfg.channels, cfg.lines, s, &timer,

@@ -282,7 +282,8 @@ struct pipe_hip_processor {
         int sections;
         bool relaxed;
     };
-    virtual bool fuse_view_fir(FirFuseView *) { return false; }
+    // prepare: the chain WILL launch the fused kernel on this stream (the history goes to its layout)
+    virtual bool fuse_view_fir(FirFuseView *, hipStream_t, bool /*prepare*/) { return false; }
     virtual int fuse_commit_fir(hipStream_t) { return PIPE_HIP_EINVAL; }  // the launch wrote hist_new
     virtual bool fuse_view_biquad(BiquadFuseView *) { return false; }
     // device-side failures that cannot be reported by the asynchronous call that caused them

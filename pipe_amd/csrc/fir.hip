@@ -66,7 +66,7 @@ struct FirArgs {
     int out_off;          // byte offset of the wave-private output slabs in LDS
     int out_slab;         // elements per slab (padded)
     int taps_off;         // byte offset of the LDS copy of the taps
-    void *hist_new;       // the other half of the history double buffer (written by this launch), TIn elements
+    double *hist_new;     // the other half of the history double buffer (written by this launch)
 };
 
 // Taps are wave-uniform and immutable during a launch: reading them through the
@@ -123,14 +123,14 @@ __device__ __forceinline__ TileCoord decode_tile(const FirArgs &a, int id)
 template <int R, typename TIn, typename TOut>
 __global__ void __launch_bounds__(kThreads)
 fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
-                  const TIn *__restrict__ hist_base, const double *__restrict__ taps_base,
+                  const double *__restrict__ hist_base, const double *__restrict__ taps_base,
                   const FirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *xs = reinterpret_cast<double *>(smem_raw);
     constexpr int kStep = R > 1 ? R + 1 : 1;
 
-    fir_history_carry(in_base, hist_base, static_cast<TIn *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
+    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
 
     // staging map: lane -> (column tx = channel, row ty = frame) by shifts
     const int tx = threadIdx.x & ((1 << a.cx_log) - 1);
@@ -197,7 +197,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         const bool ok = tx < t.cg;
         const TIn *__restrict__ src =
             in_base + (int64_t)t.line * a.line_stride + t.c0 + (ok ? tx : 0);
-        const TIn *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
+        const double *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
         for (int fb0 = ty; fb0 < nfr; fb0 += 8 * FY) {
             TIn v[8];
 #pragma unroll
@@ -216,7 +216,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                     if (g >= 0)
                         w = g <= last ? loaded : 0.0;
                     else if (g >= -(int64_t)a.H)
-                        w = (double)hist[(g + a.H) * a.C + t.c0 + tx];
+                        w = hist[(g + a.H) * a.C + t.c0 + tx];
                     xs[tx * a.plane + pad_index<R>(f)] = w;
                 }
             }
@@ -379,6 +379,15 @@ int pick_plane_stride(int minlen, int R, int lpc_log)
     return minlen;
 }
 
+// The fused chain kernel keeps a float32 stream's history as float32 (half the bytes it moves per
+// launch); every other kernel reads float64.  A chain that changes form converts: exact either way.
+template <typename TSrc, typename TDst>
+__global__ void fir_hist_convert_kernel(const TSrc *__restrict__ src, TDst *__restrict__ dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (TDst)src[i];
+}
+
 class Fir final : public pipe_hip_processor {
 public:
     int init(const double *taps, int32_t ntaps)
@@ -409,14 +418,13 @@ public:
     {
         if (hist_bytes_)
             PH_HIP(hipMemsetAsync(hist_[cur_hist_].p, 0, hist_bytes_, s));
-        hist_dtype_ = -1;  // all zeros: the next call's sample type becomes the history's
+        hist_f32_ = false;  // (all zeros: either layout)
         return PIPE_HIP_OK;
     }
 
     int start_lines(int first, int count, hipStream_t s) override
     {
-        // (no call yet since StartFunc: everything is zero already, in either layout)
-        const size_t per = hist_elem() * (size_t)H_ * (size_t)cfg.channels;
+        const size_t per = (hist_f32_ ? sizeof(float) : sizeof(double)) * (size_t)H_ * (size_t)cfg.channels;
         if (per && count > 0)
             PH_HIP(hipMemsetAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)first, 0, per * (size_t)count, s));
         return PIPE_HIP_OK;
@@ -453,15 +461,12 @@ public:
         if (frames <= 0)
             return PIPE_HIP_OK;
         last_stream_ = s;
+        PH_TRY(ensure_hist_type(false, s));  // these kernels read a float64 history
         // a window of Lines (pipe_hip_process_lines with ragged lengths): the per-Line history
         // slices of exactly those Lines
         const int nl = active_lines();
-        // the history holds the stream's own sample type (fir_hist.hpp); a stage sees one type for life
-        if (hist_dtype_ >= 0 && hist_dtype_ != in_dtype)
-            return PIPE_HIP_EINVAL;
-        hist_dtype_ = in_dtype;
-        const size_t hoff = hist_elem() * (size_t)win_first * (size_t)H_ * (size_t)cfg.channels;  // bytes
-        const void *hist = static_cast<const char *>(hist_[cur_hist_].p) + hoff;
+        const size_t hoff = (size_t)win_first * (size_t)H_ * (size_t)cfg.channels;
+        const double *hist = static_cast<const double *>(hist_[cur_hist_].p) + hoff;
         // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
@@ -502,13 +507,12 @@ public:
         return flip_history(s);
     }
 
-    bool fuse_view_fir(FirFuseView *v) override
+    bool fuse_view_fir(FirFuseView *v, hipStream_t s, bool prepare) override
     {
         if (!ols_ || windowed())
             return false;
-        if (hist_dtype_ >= 0 && hist_dtype_ != PIPE_HIP_F32)
-            return false;  // (the fused kernel reads a float32 stream)
-        hist_dtype_ = PIPE_HIP_F32;
+        if (prepare && ensure_hist_type(true, s) != PIPE_HIP_OK)  // the fused kernel: float32 history
+            return false;
         v->hist = hist_[cur_hist_].p;
         v->hist_new = hist_next();
         v->plan = &ols_->impl();
@@ -533,10 +537,28 @@ private:
         return 8 * (int64_t)cus_;
     }
 
+    // the history of all Lines into the other half of the double buffer in the other element type
+    int ensure_hist_type(bool f32, hipStream_t s)
+    {
+        if (hist_f32_ == f32 || H_ <= 0)
+            return PIPE_HIP_OK;
+        const int64_t n = (int64_t)cfg.lines * H_ * cfg.channels;
+        const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        if (f32)
+            hipLaunchKernelGGL((fir_hist_convert_kernel<double, float>), dim3(grid), dim3(256), 0, s,
+                               static_cast<const double *>(hist_[cur_hist_].p), static_cast<float *>(hist_[cur_hist_ ^ 1].p), n);
+        else
+            hipLaunchKernelGGL((fir_hist_convert_kernel<float, double>), dim3(grid), dim3(256), 0, s,
+                               static_cast<const float *>(hist_[cur_hist_].p), static_cast<double *>(hist_[cur_hist_ ^ 1].p), n);
+        PH_HIP(hipGetLastError());
+        cur_hist_ ^= 1;
+        hist_f32_ = f32;
+        return PIPE_HIP_OK;
+    }
+
     // new history = last N-1 frames of (old history ++ this call's input)
     // the launch just queued wrote the other half of the history double buffer
-    char *hist_next() const { return static_cast<char *>(hist_[cur_hist_ ^ 1].p); }
-    size_t hist_elem() const { return hist_dtype_ == PIPE_HIP_F32 ? sizeof(float) : sizeof(double); }
+    double *hist_next() const { return static_cast<double *>(hist_[cur_hist_ ^ 1].p); }
     int flip_history(hipStream_t s)
     {
         if (H_ <= 0)
@@ -544,7 +566,7 @@ private:
         if (windowed()) {
             // only the window's Lines were advanced: bring their new history back into the
             // current half instead of flipping the halves of every Line
-            const size_t per = hist_elem() * (size_t)H_ * (size_t)cfg.channels;
+            const size_t per = sizeof(double) * (size_t)H_ * (size_t)cfg.channels;
             PH_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_hist_].p) + per * (size_t)win_first,
                                   static_cast<const char *>(hist_[cur_hist_ ^ 1].p) + per * (size_t)win_first,
                                   per * (size_t)win_count, hipMemcpyDeviceToDevice, s));
@@ -630,7 +652,7 @@ private:
 
     template <int R>
     int launch_r(int in_dtype, int out_dtype, const Geometry &g, const void *d_in, void *d_out,
-                 const void *hist, const double *taps, const FirArgs &a, hipStream_t s)
+                 const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
 #define PH_FIR_LAUNCH(TI, TO, NAME)                                                                  \
     do {                                                                                             \
@@ -642,8 +664,7 @@ private:
         hipEvent_t ev_a = nullptr, ev_b = nullptr;                                                   \
         PH_TRY(timer.pair(&ev_a, &ev_b));                                                            \
         hipExtLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, ev_a, ev_b, 0,                    \
-                              static_cast<const TI *>(d_in), static_cast<TO *>(d_out),                 \
-                              static_cast<const TI *>(hist), taps, a);                                 \
+                              static_cast<const TI *>(d_in), static_cast<TO *>(d_out), hist, taps, a); \
         last_kernel = NAME;                                                                          \
     } while (0)
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
@@ -678,7 +699,7 @@ private:
     }
 
     int launch(const Geometry &g, int in_dtype, int out_dtype, const void *d_in, void *d_out,
-               const void *hist, const double *taps, const FirArgs &a, hipStream_t s)
+               const double *hist, const double *taps, const FirArgs &a, hipStream_t s)
     {
         switch (g.R) {
         case 16: return launch_r<16>(in_dtype, out_dtype, g, d_in, d_out, hist, taps, a, s);
@@ -699,7 +720,7 @@ private:
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;
     int cur_taps_ = 0, cur_hist_ = 0;
-    int hist_dtype_ = -1;  // sample type of the history's elements (-1: all zeros, not fixed yet)
+    bool hist_f32_ = false;  // the history is in the fused chain kernel's float32 layout
     bool exact_ = std::getenv("PIPE_HIP_FIR_EXACT") != nullptr;
     std::unique_ptr<ols::Plan> ols_;
 };

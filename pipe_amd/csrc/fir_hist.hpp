@@ -1,7 +1,6 @@
 // The FIR's history carry, shared by the direct and the overlap-save kernels:
 //     new history = last H frames of (old history ++ this call's input)      per Line.
-// The history is kept in the stream's own sample type (float32 streams: half the bytes of a float64
-// history, and exact) and double-buffered (the kernels read `hist_old`, the next call reads
+// The history is double-buffered (the kernels read `hist_old`, the next call reads
 // `hist_new`), so every main kernel writes the next history itself, spread over the first
 // threads of its grid, instead of a follow-up launch.
 #pragma once
@@ -12,9 +11,11 @@
 
 namespace pipehip {
 
-template <typename TIn>
-__device__ __forceinline__ void fir_history_carry(const TIn *__restrict__ in, const TIn *__restrict__ hist_old,
-                                                  TIn *__restrict__ hist_new, int64_t frames,
+// THist: float64 everywhere but in the fused chain kernel, which keeps a float32 stream's history
+// as float32 (exact, half the bytes: fir.hip converts when a chain changes form).
+template <typename TIn, typename THist>
+__device__ __forceinline__ void fir_history_carry(const TIn *__restrict__ in, const THist *__restrict__ hist_old,
+                                                  THist *__restrict__ hist_new, int64_t frames,
                                                   int64_t line_stride, int H, int C, int lines)
 {
     const int64_t per_line = (int64_t)H * C;
@@ -26,7 +27,7 @@ __device__ __forceinline__ void fir_history_carry(const TIn *__restrict__ in, co
         const int j = r / C;
         const int c = r - j * C;
         const int64_t s = frames - H + j;
-        const TIn v = s >= 0 ? in[line * line_stride + s * C + c] : hist_old[(line * H + (s + H)) * C + c];
+        const THist v = s >= 0 ? (THist)in[line * line_stride + s * C + c] : hist_old[(line * H + (s + H)) * C + c];
         hist_new[(line * H + j) * C + c] = v;
     }
 }

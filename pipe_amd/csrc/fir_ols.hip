@@ -131,7 +131,7 @@ struct Args {
     int64_t nitems;       // lines * pairs * tiles_per_line
     int d_pair, d_tile, d_line;  // the wave stride of the launch as (pair, tile, Line) digits
     int group;                   // waves of a block that take consecutive items
-    void *hist_new;              // the other half of the history double buffer (written here), TIn elements
+    double *hist_new;            // the other half of the history double buffer (written here)
 };
 
 // exchange addresses (in doubles, inside the wave-private buffer)
@@ -148,7 +148,7 @@ __device__ __forceinline__ int ex1_addr(int n1, int k2) { return 65 * k2 + n1; }
 template <typename TIn, typename TOut, int WAVES, bool VEC>
 __global__ void __launch_bounds__(WAVES * 64)
 fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
-               const TIn *__restrict__ hist_base, const double2 *__restrict__ tw1_g,
+               const double *__restrict__ hist_base, const double2 *__restrict__ tw1_g,
                const double2 *__restrict__ tw2_g, const double2 *__restrict__ hperm_g, const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -161,7 +161,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     constexpr bool PREFETCH = WAVES <= 8;
     double2 *exbase = tw2s + 4 * 16;                         // [WAVES][kEx] wave-private exchange
 
-    fir_history_carry(in_base, hist_base, static_cast<TIn *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
+    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < kHalf; i += WAVES * 64)
         hspec[i] = hperm_g[i];
     for (int i = threadIdx.x; i < 15 * 64; i += WAVES * 64)
@@ -313,7 +313,7 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         } else {
             // a Line's first tile (its head is the history) and odd / unaligned layouts
             const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-            const TIn *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+            const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t g = fr0 + n1 + 64 * r;
@@ -325,9 +325,9 @@ fir_ols_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                             im = (double)in[g * a.C + c0 + 1];
                     }
                 } else if (g >= -(int64_t)a.H) {
-                    re = (double)hist[(g + a.H) * a.C + c0];
+                    re = hist[(g + a.H) * a.C + c0];
                     if (two)
-                        im = (double)hist[(g + a.H) * a.C + c0 + 1];
+                        im = hist[(g + a.H) * a.C + c0 + 1];
                 }
                 v[r] = cd{re, im};
             }
@@ -525,7 +525,7 @@ int64_t Plan::items(int64_t frames, int channels, int lines) const
 }
 
 template <typename TIn, typename TOut, int WAVES, bool VEC>
-static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const void *hist, Args a,
+static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, Args a,
                       hipStream_t s, KernelTimer *timer)
 {
     auto kfn = fir_ols_kernel<TIn, TOut, WAVES, VEC>;
@@ -555,13 +555,13 @@ static int launch_ols(const Plan::Impl &I, const void *d_in, void *d_out, const 
     if (timer)
         PH_TRY(timer->pair(&ev_a, &ev_b));
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
-                       static_cast<TOut *>(d_out), static_cast<const TIn *>(hist), static_cast<const double2 *>(I.tw1.p),
+                       static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw1.p),
                        static_cast<const double2 *>(I.tw2.p), static_cast<const double2 *>(I.hperm[I.cur].p), a);
     PH_HIP(hipGetLastError());
     return PIPE_HIP_OK;
 }
 
-int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const void *hist, void *hist_new,
+int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, double *hist_new,
               int64_t frames,
               int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {

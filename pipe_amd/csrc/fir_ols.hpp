@@ -25,7 +25,7 @@ public:
     // work items (wave-sized 1024-point transforms) a call of this size launches
     int64_t items(int64_t frames, int channels, int lines) const;
     // advance every Line by `frames` frames; `hist` = the (N-1) frames before the call
-    int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const void *hist, void *hist_new,
+    int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, double *hist_new,
             int64_t frames,
             int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer = nullptr);
 

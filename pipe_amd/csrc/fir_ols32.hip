@@ -34,7 +34,7 @@ constexpr int kHalf = kHalf32;
 constexpr int kPlane = kPlane32;
 
 template <typename TIn, typename TOut>
-int launch32(const Plan::Impl &I, const void *d_in, void *d_out, const void *hist, Args32 a, hipStream_t s,
+int launch32(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, Args32 a, hipStream_t s,
              KernelTimer *timer)
 {
     auto kfn = fir_ols32_kernel<TIn, TOut, 0>;
@@ -51,7 +51,7 @@ int launch32(const Plan::Impl &I, const void *d_in, void *d_out, const void *his
     if (timer)
         PH_TRY(timer->pair(&ev_a, &ev_b));
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
-                          static_cast<TOut *>(d_out), static_cast<const TIn *>(hist), static_cast<const double2 *>(I.tw32.p),
+                          static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw32.p),
                           static_cast<const double2 *>(I.hperm[I.cur].p), a, FuseArgs{}, FuseConst<1>{});
     PH_HIP(hipGetLastError());
     return PIPE_HIP_OK;
@@ -73,8 +73,8 @@ int init_ols32_tables(Plan::Impl *I)
     return PIPE_HIP_OK;
 }
 
-int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int out_dtype, const void *hist,
-              void *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
+int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist,
+              double *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
               KernelTimer *timer)
 {
     Args32 a{};

@@ -19,8 +19,8 @@ struct Plan::Impl {
 
 // fir_ols32.hip
 int init_ols32_tables(Plan::Impl *I);
-int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int out_dtype, const void *hist,
-              void *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
+int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist,
+              double *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
               KernelTimer *timer);
 
 }  // namespace ols

@@ -51,7 +51,7 @@ struct Args32 {
     int local;            // fused chain: every Line's tiles run in ONE workgroup, records in LDS (below)
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
-    void *hist_new;       // TIn elements
+    void *hist_new;       // float64 elements (S = 0), the stream's float32 (fused chain, S > 0)
 };
 
 // ---- the biquad + gain epilogue of the fused chain (chain_fused.hip) ---------------------------
@@ -646,11 +646,22 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     }
 }
 
+// element type of the FIR history a kernel reads and writes
+template <typename TIn, int S>
+struct HistOf {
+    using type = double;
+};
+template <int S>
+struct HistOf<float, S> {
+    using type = typename std::conditional<(S > 0), float, double>::type;
+};
+
 // S = 0: the FIR alone.  S = 1, 2: the FIR's tile goes through an S-section biquad cascade and a
 // gain before it is stored (chain_fused.hip; fa / fc are then the epilogue's arguments).
 template <typename TIn, typename TOut, int S = 0, bool GENERAL = false, bool LOCAL = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
-fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const TIn *__restrict__ hist_base,
+fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
+                 const typename HistOf<TIn, S>::type *__restrict__ hist_base,
                  const double2 *__restrict__ tw_g, const double2 *__restrict__ hperm_g, const Args32 a,
                  const FuseArgs fa, const FuseConst<(S > 0 ? S : 1)> fc)
 {
@@ -668,7 +679,8 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
             round_done[threadIdx.x] = 0;
     }
 
-    fir_history_carry(in_base, hist_base, static_cast<TIn *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
+    fir_history_carry(in_base, hist_base, static_cast<typename HistOf<TIn, S>::type *>(a.hist_new), a.frames, a.line_stride,
+                      a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
         hspec[i] = hperm_g[i];
     for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
@@ -769,7 +781,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, c
         } else {
             // a Line's first tile: its head is the history
             const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-            const TIn *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+            const typename HistOf<TIn, S>::type *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
             const int64_t fr0 = (int64_t)tile * a.L - a.HP;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
