@@ -180,25 +180,28 @@ __device__ __forceinline__ void resample_taps(const double *__restrict__ hp, con
 }
 
 template <typename TIn, typename TOut, int TT>
-__global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArgs t)
+__global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArgs t)  // (launched with 64..256 threads)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const ResampleArgs &a = t.r;
-    double *tab = reinterpret_cast<double *>(smem_raw);  // [T][up]
-    double *xs = tab + (size_t)a.T * a.up;                // [C][plane]
+    const int nthr = (int)blockDim.x;
+    // taps in registers (TT > 0): no table in LDS at all -- the lane's T taps come from global memory
+    // once per launch -- so a workgroup is its planes only and more of them share a CU
+    double *tab = reinterpret_cast<double *>(smem_raw);           // [T][up]   (TT == 0)
+    double *xs = TT > 0 ? tab : tab + (size_t)a.T * a.up;          // [C][plane]
     const int H = a.T - 1;
-    {   // proto is already [p + j*up]; staged once per (persistent) workgroup, 8 loads in flight
+    if constexpr (TT == 0) {   // proto is already [p + j*up]; staged once per (persistent) workgroup, 8 loads in flight
         const int ntab = a.T * a.up;
-        for (int k0 = threadIdx.x; k0 < ntab; k0 += 8 * kThreads) {
+        for (int k0 = threadIdx.x; k0 < ntab; k0 += 8 * nthr) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * kThreads;
+                const int k = k0 + u * nthr;
                 v[u] = a.proto[k < ntab ? k : 0];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * kThreads;
+                const int k = k0 + u * nthr;
                 if (k < ntab)
                     tab[k] = v[u];
             }
@@ -210,12 +213,11 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
     // h[j] = proto[p + j*up] are fetched once
     double hreg[TT > 0 ? TT : 1];
     if constexpr (TT > 0) {
-        __syncthreads();  // the table is complete
         const unsigned r_call = (unsigned)((a.out_total * a.down) % a.up);
         const unsigned p = (r_call + (unsigned)threadIdx.x * (unsigned)a.down) % (unsigned)a.up;
 #pragma unroll
         for (int j = 0; j < TT; ++j)
-            hreg[j] = tab[p + j * a.up];
+            hreg[j] = a.proto[p + j * a.up];
     }
 
     const int ntiles = t.tiles_per_line * a.lines;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
     {
         const int tx = threadIdx.x & ((1 << t.cx_log) - 1);
         const int ty = threadIdx.x >> t.cx_log;
-        const int FY = kThreads >> t.cx_log;
+        const int FY = nthr >> t.cx_log;
         const bool ok = tx < a.C;
         const int64_t last = a.in_frames - 1;
         const TIn *__restrict__ src = in + (ok ? tx : 0);
@@ -401,9 +403,11 @@ public:
         const bool reg_taps = (T_ == 8 || T_ == 12 || T_ == 16 || T_ == 24 || T_ == 32) && up_ <= kThreads &&
                               !std::getenv("PIPE_HIP_RESAMPLE_LDS_TAPS");
         const int q = reg_taps ? up_ * (kThreads / up_) : kThreads;
-        // outputs per tile: kOutTile, halved until table + planes fit the 64 KB a workgroup may take
-        // (wide Lines: 8 channels at 160 x 24 take tiles of 480 and stay on this kernel: 95 us where
-        // the gather kernel takes 213) -- never below one output per computing lane
+        // (taps in registers: as many waves as hold the q computing lanes, e.g. 3 for 160)
+        const int threads = reg_taps ? (q + 63) / 64 * 64 : kThreads;
+        // outputs per tile: kOutTile, halved until the workgroup's LDS -- planes, and the table unless
+        // the taps sit in registers -- fits 64 KB (wide Lines: 8 channels at 160 x 24 stay on this
+        // kernel: 74 us where the gather kernel takes 213) -- never below one output per computing lane
         int tile_out = 0, win = 0, plane = 0;
         size_t lds = 0;
         for (int cap = kOutTile; cap >= q; cap /= 2) {
@@ -412,7 +416,7 @@ public:
             win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
             plane = win + 1;
             plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
-            lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
+            lds = sizeof(double) * ((reg_taps ? 0 : (size_t)T_ * up_) + (size_t)plane * cfg.channels);
             if (lds <= 64 * 1024)
                 break;
         }
@@ -429,19 +433,19 @@ public:
             t.q = q;
             t.tiles_per_line = (int)((n_out + tile_out - 1) / tile_out);
             const int64_t ntiles = (int64_t)t.tiles_per_line * cfg.lines;
-            const int64_t slots = 3 * 256;  // ~3 workgroups per CU keep the table amortised
+            const int64_t slots = (reg_taps ? 4 : 3) * 256;  // workgroups resident per CU (registers bound them: 12 waves)
             const int64_t per = (ntiles + slots - 1) / slots;
             const dim3 grid((unsigned)((ntiles + per - 1) / per));
             PH_TRY(timer.begin(s));
 #define PH_RS(TI, TO, NAME)                                                                              \
     do {                                                                                                 \
         switch (reg_taps ? T_ : 0) {                                                                     \
-        case 8: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 8>), grid, dim3(kThreads), lds, s, t); break;   \
-        case 12: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 12>), grid, dim3(kThreads), lds, s, t); break; \
-        case 16: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(kThreads), lds, s, t); break; \
-        case 24: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(kThreads), lds, s, t); break; \
-        case 32: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(kThreads), lds, s, t); break; \
-        default: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(kThreads), lds, s, t); break;  \
+        case 8: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 8>), grid, dim3(threads), lds, s, t); break;   \
+        case 12: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 12>), grid, dim3(threads), lds, s, t); break; \
+        case 16: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(threads), lds, s, t); break; \
+        case 24: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(threads), lds, s, t); break; \
+        case 32: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(threads), lds, s, t); break; \
+        default: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(threads), lds, s, t); break;  \
         }                                                                                                \
         last_kernel = NAME;                                                                              \
     } while (0)
