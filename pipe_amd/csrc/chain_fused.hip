@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -381,10 +382,29 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     if (timer)
         PH_TRY(timer->pair(&ev_a, &ev_b));
+    // Tiles of the global look-back wait for tiles of OTHER workgroups of the same launch, so the
+    // whole grid must be resident at once.  Two such launches on two streams could each get half the
+    // CUs and wait for their other halves: launches of this form on one device therefore run one
+    // after the other (an event chain; the block-local form has no such waits and is not chained).
+    static std::mutex chain_mu;
+    static hipEvent_t chain_done[64] = {};
+    std::unique_lock<std::mutex> chain_lock(chain_mu, std::defer_lock);
+    int dev = 0;
+    if constexpr (!LOCAL) {
+        PH_HIP(hipGetDevice(&dev));
+        dev &= 63;
+        chain_lock.lock();  // wait + launch + record as one step: no other launch of this form slips in between
+        if (!chain_done[dev])
+            PH_HIP(hipEventCreateWithFlags(&chain_done[dev], hipEventDisableTiming));
+        else
+            PH_HIP(hipStreamWaitEvent(s, chain_done[dev], 0));
+    }
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const float *>(d_in),
                           static_cast<float *>(d_out), static_cast<const float *>(hist), static_cast<const double2 *>(P.tw32.p),
                           static_cast<const double2 *>(P.hperm[P.cur].p), a, fa, fc);
     PH_HIP(hipGetLastError());
+    if constexpr (!LOCAL)
+        PH_HIP(hipEventRecord(chain_done[dev], s));
 #ifdef PH_FUSE_PROF
     {
         static int launches = 0;

@@ -197,3 +197,47 @@ def test_block_local_look_back_equals_the_global_one(lines, C, calls, monkeypatc
     for l in (0, 1, lines // 2, lines - 1):
         d = ulps(got[l], oracle_chain(taps, LOWPASS, 0.5, x[l]))
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
+
+
+def test_two_global_look_back_chains_on_two_streams(monkeypatch):
+    """Tiles of the global look-back wait for tiles of other workgroups of their launch: two such
+    launches sharing the device's CUs could starve each other, so chain_fused.hip runs launches of that
+    form on one device one after the other.  Two chains driven from two threads, each on its own
+    stream, 40 calls each: both streams stay the oracle's and nothing gives up (flush reports it)."""
+    import threading
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, F, calls = 200, 8, 4096, 25         # fewer Lines than CUs: the global form, 256 workgroups a launch
+    taps = synth.fir_lowpass_taps(256, f32_rounded=True)
+    xs = [np.random.default_rng(70 + k).uniform(-1, 1, size=(lines, F * calls, C)).astype(np.float32) for k in range(2)]
+    outs, names, errs = [None, None], [None, None], []
+
+    def drive(k):
+        try:
+            kw = dict(dtype=np.float32, lines=lines, max_batch=1)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                with P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(LOWPASS, F, C, **kw), P.Gain(0.5, F, C, **kw)]) as p:
+                    p.start()
+                    d_in = torch.from_numpy(xs[k]).cuda()
+                    ys = []
+                    for i in range(calls):
+                        xin = d_in[:, i * F:(i + 1) * F, :].contiguous()
+                        y = torch.empty_like(xin)
+                        p.process_batch(xin, y, F)
+                        ys.append(y)
+                    st.synchronize()
+                    p.flush()
+                    names[k] = p.kernel_name()
+                    outs[k] = torch.cat(ys, dim=1).cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=drive, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for k in range(2):
+        assert "chain_fused" in names[k] and "local" not in names[k], names[k]
+        for l in (0, lines - 1):
+            d = ulps(outs[k][l], oracle_chain(taps, LOWPASS, 0.5, xs[k][l]))
+            assert d.max() <= 1.0, f"chain {k} line {l}: {d.max()} ulp"
