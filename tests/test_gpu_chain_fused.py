@@ -241,3 +241,58 @@ def test_two_global_look_back_chains_on_two_streams(monkeypatch):
         for l in (0, lines - 1):
             d = ulps(outs[k][l], oracle_chain(taps, LOWPASS, 0.5, xs[k][l]))
             assert d.max() <= 1.0, f"chain {k} line {l}: {d.max()} ulp"
+
+
+@pytest.mark.parametrize("lines", [24, 256], ids=["global", "local"])
+def test_mutations_between_fused_launches(lines, monkeypatch):
+    """mutable.Mutation on a fused chain (pipe.go:433: applied before the ProcessFunc of the buffer it
+    travels with): new taps (the tap spectrum is re-uploaded on the launch stream), new biquad
+    coefficients (the look-back matrices are rebuilt, the cascade's state carries over), a new gain --
+    each takes effect at the next launch and at no other."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    from pipe_amd import _lib as L_
+    C, F = 4, 4096
+    h1 = synth.fir_lowpass_taps(256, f32_rounded=True)
+    h2 = synth.fir_lowpass_taps(256, fc=0.1, f32_rounded=True)
+    q1, q2 = synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(3000.0, q=1.5)
+    g1, g2 = 0.5, 2.0
+    x = np.random.default_rng(lines).uniform(-1, 1, size=(lines, 6 * F, C)).astype(np.float32)
+    kw = dict(dtype=np.float32, lines=lines, max_batch=1)
+    with P.Chain([P.Fir(h1, F, C, **kw), P.Biquad(q1, F, C, **kw), P.Gain(g1, F, C, **kw)]) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        ys, names = [], []
+        for k in range(6):
+            if k == 1:
+                p.set_stage_param(0, L_.PARAM_TAPS, h2)
+            if k == 2:
+                p.set_stage_param(1, L_.PARAM_COEFFS, q2)
+            if k == 3:
+                p.set_stage_param(2, L_.PARAM_GAIN, [g2])
+            if k == 5:
+                p.set_stage_param(0, L_.PARAM_TAPS, h1)
+                p.set_stage_param(1, L_.PARAM_COEFFS, q1)
+            xin = d_in[:, k * F:(k + 1) * F, :].contiguous()
+            y = torch.empty_like(xin)
+            p.process_batch(xin, y, F)
+            names.append(p.kernel_name())
+            ys.append(y)
+        p.flush()
+        torch.cuda.synchronize()
+    got = torch.cat(ys, dim=1).cpu().numpy()
+    assert all("chain_fused" in n for n in names) and (lines < 256 or all("local" in n for n in names)), names
+    for l in (0, lines - 1):
+        fir, bq = O.Fir(h1, C), O.Biquad(q1, C)
+        want = []
+        for k in range(6):
+            if k == 1:
+                fir.set_taps(h2)
+            if k == 2:
+                bq.set_coeffs(q2)
+            if k == 5:
+                fir.set_taps(h1)
+                bq.set_coeffs(q1)
+            yk = bq.process(fir.process(x[l, k * F:(k + 1) * F].astype(np.float64)))
+            want.append(O.gain(yk, g2 if k >= 3 else g1).reshape(F, C))
+        d = ulps(got[l], np.concatenate(want))
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at frame {np.argmax(d) // C}"
