@@ -104,6 +104,11 @@ __device__ __forceinline__ void lds_read_run(double (&v)[N], unsigned addr, std:
 // all but the CNT most recent LDS reads have landed (the LDS returns in order); the values pass
 // through so that their uses stay behind the wait
 template <int CNT>
+__device__ __forceinline__ void lds_wait(double (&a)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(CNT));
+}
+template <int CNT>
 __device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[4])
 {
     asm volatile("s_waitcnt lgkmcnt(%8)"
@@ -157,6 +162,40 @@ __device__ __forceinline__ void resample_taps_reg(const double (&h)[TT > 0 ? TT 
         o[c] = (TOut)acc[c];
 }
 
+// float32 stream, window kept as float32 {channel 2p, channel 2p + 1} pairs: ONE ds_read_b64 brings a
+// frame of both channels (the float64 planes need two), widened in registers -- the kernel is bound by
+// the number of LDS reads in flight, not by the VALU.  Eight taps a group, the next group requested
+// before the current one is waited for.
+template <int TT, typename TOut>
+__device__ __forceinline__ void resample_taps_reg_f32pair(const double (&h)[TT], const double *__restrict__ xp,
+                                                          TOut *__restrict__ o)
+{
+    static_assert(TT % 4 == 0, "four taps a group");
+    typedef __attribute__((address_space(3))) const double *lds_ptr;
+    const unsigned a0 = (unsigned)(uintptr_t)(lds_ptr)xp;  // LDS byte address of the pair's frame x[0]
+    double acc0 = 0.0, acc1 = 0.0;
+    double v[2][4];
+    lds_read_run<4>(v[0], a0 - 8u * 3u, std::make_integer_sequence<int, 4>{});
+#pragma unroll
+    for (int g = 0; g < TT / 4; ++g) {
+        const int j0 = 4 * g;
+        if (g + 1 < TT / 4) {
+            lds_read_run<4>(v[(g + 1) & 1], a0 - 8u * (unsigned)(j0 + 7), std::make_integer_sequence<int, 4>{});
+            lds_wait<4>(v[g & 1]);
+        } else {
+            lds_wait<0>(v[g & 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 f = __builtin_bit_cast(float2, v[g & 1][i]);
+            acc0 = __builtin_fma(h[j0 + i], (double)f.x, acc0);
+            acc1 = __builtin_fma(h[j0 + i], (double)f.y, acc1);
+        }
+    }
+    o[0] = (TOut)acc0;
+    o[1] = (TOut)acc1;
+}
+
 template <int CH, typename TOut>
 __device__ __forceinline__ void resample_taps(const double *__restrict__ hp, const double *__restrict__ xp,
                                               int T, int up, int plane, TOut *__restrict__ o)
@@ -179,9 +218,10 @@ __device__ __forceinline__ void resample_taps(const double *__restrict__ hp, con
         o[c] = (TOut)acc[c];
 }
 
-template <typename TIn, typename TOut, int TT>
+template <typename TIn, typename TOut, int TT, bool F32WIN = false>
 __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArgs t)  // (launched with 64..256 threads)
 {
+    static_assert(!F32WIN || (TT > 0 && sizeof(TIn) == 4), "the float32 pair window: float32 streams, taps in registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const ResampleArgs &a = t.r;
     const int nthr = (int)blockDim.x;
@@ -261,7 +301,10 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
                         w = g <= last ? loaded : 0.0;
                     else if (g >= -(int64_t)H)
                         w = hist[(g + H) * a.C + tx];
-                    xs[tx * t.plane + f] = w;
+                    if constexpr (F32WIN)  // {channel 2p, 2p + 1} of a frame side by side, plane p
+                        reinterpret_cast<float *>(xs)[((size_t)(tx >> 1) * t.plane + f) * 2 + (tx & 1)] = (float)w;
+                    else
+                        xs[tx * t.plane + f] = w;
                 }
             }
         }
@@ -281,7 +324,10 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
             const int left = a.C - c0;
             const double *__restrict__ xp = x + c0 * t.plane;
             TOut *__restrict__ o = out + (int64_t)ml * a.C + c0;
-            if constexpr (TT > 0) {
+            if constexpr (F32WIN) {
+                resample_taps_reg_f32pair<TT>(hreg, xs + (size_t)(c0 >> 1) * t.plane + nrel + H, o);
+                c0 += 2;
+            } else if constexpr (TT > 0) {
                 if (left >= 4 && TT % 4 != 0) {  // (channel pairs take the ds_read_b64 form: resample_taps_reg)
                     resample_taps_reg<4, TT>(hreg, xp, t.plane, o);
                     c0 += 4;
@@ -408,6 +454,10 @@ public:
         // outputs per tile: kOutTile, halved until the workgroup's LDS -- planes, and the table unless
         // the taps sit in registers -- fits 64 KB (wide Lines: 8 channels at 160 x 24 stay on this
         // kernel: 74 us where the gather kernel takes 213) -- never below one output per computing lane
+        // float32 streams with the taps in registers keep the window as float32 channel pairs
+        // (from four channels on: with two the float64 planes are faster, 51.5 against 59.7 us)
+        const bool f32win = reg_taps && in_dtype == PIPE_HIP_F32 && cfg.channels % 2 == 0 && cfg.channels >= 4 && T_ % 4 == 0 &&
+                            !std::getenv("PIPE_HIP_RESAMPLE_F64_PLANES");
         int tile_out = 0, win = 0, plane = 0;
         size_t lds = 0;
         for (int cap = kOutTile; cap >= q; cap /= 2) {
@@ -416,7 +466,7 @@ public:
             win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
             plane = win + 1;
             plane += (16 - plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): channel planes on distinct banks
-            lds = sizeof(double) * ((reg_taps ? 0 : (size_t)T_ * up_) + (size_t)plane * cfg.channels);
+            lds = sizeof(double) * ((reg_taps ? 0 : (size_t)T_ * up_) + (size_t)plane * (f32win ? cfg.channels / 2 : cfg.channels));
             if (lds <= 64 * 1024)
                 break;
         }
@@ -449,7 +499,22 @@ public:
         }                                                                                                \
         last_kernel = NAME;                                                                              \
     } while (0)
-            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+#define PH_RS32(TO, NAME)                                                                                         \
+    do {                                                                                                          \
+        switch (T_) {                                                                                             \
+        case 8: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 8, true>), grid, dim3(threads), lds, s, t); break;   \
+        case 12: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 12, true>), grid, dim3(threads), lds, s, t); break; \
+        case 16: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 16, true>), grid, dim3(threads), lds, s, t); break; \
+        case 24: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 24, true>), grid, dim3(threads), lds, s, t); break; \
+        default: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 32, true>), grid, dim3(threads), lds, s, t); break; \
+        }                                                                                                         \
+        last_kernel = NAME;                                                                                       \
+    } while (0)
+            if (f32win && out_dtype == PIPE_HIP_F32)
+                PH_RS32(float, "resample_tiled_kernel<f32,f32,pairs>");
+            else if (f32win)
+                PH_RS32(double, "resample_tiled_kernel<f32,f64,pairs>");
+            else if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
                 PH_RS(float, float, "resample_tiled_kernel<f32,f32>");
             else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
                 PH_RS(double, double, "resample_tiled_kernel<f64,f64>");
@@ -457,6 +522,7 @@ public:
                 PH_RS(float, double, "resample_tiled_kernel<f32,f64>");
             else
                 PH_RS(double, float, "resample_tiled_kernel<f64,f32>");
+#undef PH_RS32
 #undef PH_RS
             PH_HIP(hipGetLastError());
             PH_TRY(timer.end(s));
