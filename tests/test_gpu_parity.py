@@ -270,6 +270,44 @@ def test_resampler_streaming_bit_exact(dtype, up, down):
             pos += n
 
 
+@pytest.mark.parametrize("channels,T,up,down", [(4, 24, 160, 147), (8, 8, 3, 2), (6, 16, 2, 3), (8, 24, 147, 160)])
+def test_resampler_wide_float32_lines_take_the_pair_window_and_stay_bit_exact(channels, T, up, down):
+    """float32 streams of four or more channels keep the staged window as float32 channel pairs (one LDS
+    read per frame and pair, widened in registers): exact, so still the oracle's bits -- per buffer with a
+    carried history, and as one device-resident batch of several Lines."""
+    F, lines = 2048, 3
+    proto = synth.resampler_proto(up, down, T)
+    lens = [F, 5, F, 777, 0, F]
+    cap = -(-F * up // down) + 1
+    x = sig(31, sum(lens), channels, np.float32)
+    ref = O.Resampler(proto, T, up, down, channels)
+    with P.Resampler(proto, T, up, down, F, channels, dtype=np.float32) as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n], out_cap_frames=cap)
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(-1, channels), np.float32)
+            assert got.shape == want.shape and np.array_equal(got, want), (pos, n)
+            if n:
+                assert p.kernel_name().endswith("pairs>"), p.kernel_name()
+            pos += n
+    # one launch over three Lines x four buffers
+    K = 4
+    xb = np.stack([sig(40 + l, K * F, channels, np.float32) for l in range(lines)])
+    capb = -(-K * F * up // down) + 1
+    with P.Resampler(proto, T, up, down, F, channels, dtype=np.float32, lines=lines, max_batch=K) as p:
+        p.start()
+        d_in = torch.from_numpy(xb).cuda()
+        d_out = torch.empty(lines * capb * channels, dtype=torch.float32, device="cuda")
+        n_out = p.resample_batch(d_in, K * F, d_out, capb)
+        torch.cuda.synchronize()
+        assert p.kernel_name().endswith("pairs>")
+        got = d_out.cpu().numpy().reshape(lines, capb, channels)[:, :n_out]
+    for l in range(lines):
+        want = O.Resampler(proto, T, up, down, channels).process(xb[l].astype(np.float64)).reshape(-1, channels)
+        assert n_out == want.shape[0] and np.array_equal(got[l], want.astype(np.float32)), l
+
+
 def test_resampler_config5_capacity_contract():
     # SURVEY.md F6: 4096 frames @44.1k -> 4459 @48k cannot fit ProcessFunc's 4096-frame out
     from pipe_amd._lib import ECAP, PipeHipError
