@@ -66,7 +66,8 @@ typedef enum pipe_hip_param {
                                   the window's full scale, NOT to a quiet sample next to loud ones
                                   (stop-band outputs can be off by many of THEIR ulps).  The
                                   biquad's relaxed forms propagate segment states through powers of
-                                  the state-transition matrix: sound for stable sections only.
+                                  the state-transition matrix; a cascade with a section whose poles
+                                  are not strictly inside the unit circle always takes the exact form.
                                   float64 buffers always take the exact form.
                                   On a chain it applies to every stage.  The relaxed forms mix
                                   the samples of a 1024-frame window / a segment, so a NaN or Inf

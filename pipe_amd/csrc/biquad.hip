@@ -32,6 +32,7 @@
 // damps.  The float32 result therefore equals the oracle's except where the float64 value
 // sits within ~1e-15 of a rounding boundary (then: the neighbouring float32, 1 ulp) -- the same
 // contract as the FIR's overlap-save form ("the one tolerance").
+#include <cmath>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -496,7 +497,8 @@ public:
         const unsigned sblocks = (unsigned)((a.nseries + kThreads - 1) / kThreads);
         // time-segmented form: float32 results (or float64 intermediates of a float32 chain)
         // only, and only when the series alone cannot fill the machine
-        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out);
+        // (the relaxed forms carry states through powers of the transition matrix: stable sections only)
+        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && stable();
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
         bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
                          frames * a.nseries >= seg_min_samples_;
@@ -657,7 +659,20 @@ public:
         v->state = static_cast<double *>(state_.p);
         v->coeffs = &q_.c[0][0];
         v->sections = S_;
-        v->relaxed = !exact_ && !env_exact_;
+        v->relaxed = !exact_ && !env_exact_ && stable();
+        return true;
+    }
+
+    // every section's poles strictly inside the unit circle (the stability triangle of 1 + a1 z^-1 +
+    // a2 z^-2): |a2| < 1 and |a1| < 1 + a2.  Anything else -- an integrator, a deliberately unstable
+    // test section, NaN coefficients -- keeps the ordered recurrence, which is what the oracle does.
+    bool stable() const
+    {
+        for (int s = 0; s < S_; ++s) {
+            const double a1 = q_.c[s][3], a2 = q_.c[s][4];
+            if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2))
+                return false;
+        }
         return true;
     }
 

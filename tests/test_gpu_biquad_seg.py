@@ -122,3 +122,31 @@ def test_config3_chain_uses_both_relaxed_forms_and_stays_within_one_ulp(monkeypa
         d = np.abs(got[l].astype(np.float64) - want.astype(np.float64))
         assert np.all(d <= ulp)
         assert np.count_nonzero(got[l] != want) <= 4
+
+
+def test_sections_that_are_not_strictly_stable_keep_the_ordered_recurrence(monkeypatch):
+    """The relaxed forms (time-segmented biquad, fused chain) carry segment states through powers of
+    the state-transition matrix -- sound for poles strictly inside the unit circle only.  An integrator
+    (pole on the circle) and a mildly unstable section take the exact kernels whatever the call size:
+    bit for bit the oracle's ordered recurrence."""
+    monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, F = 8, 2, 8192
+    x = np.stack([synth.samples(synth.line_seed(70 + l), 0, F * C, np.float32).reshape(F, C) for l in range(lines)]) * 1e-3
+    # y[n] = x[n] + y[n-1] (pole at 1); poles at radius sqrt(1.0005) on the imaginary axis
+    for q in (np.array([[1.0, 0.0, 0.0, -1.0, 0.0]]), np.array([[1.0, 0.0, 0.0, 0.0, 1.0005]])):
+        got, name = run(q, x, lines, 2, exact=False)
+        assert "segmented" not in name, name
+        want = oracle(q, x).astype(np.float32)
+        assert np.array_equal(got, want)
+    # and in a chain: FIR -> such a section never takes the fused kernel
+    h = synth.fir_lowpass_taps(64, f32_rounded=True)
+    q = np.array([[1.0, 0.0, 0.0, -1.0, 0.0]])
+    kw = dict(dtype=np.float32, lines=lines)
+    with P.Chain([P.Fir(h, F, C, **kw), P.Biquad(q, F, C, **kw)]) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        p.process_batch(d_in, d_out, F)
+        torch.cuda.synchronize()
+        assert "chain_fused" not in p.kernel_name(), p.kernel_name()
