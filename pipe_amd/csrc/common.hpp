@@ -161,10 +161,14 @@ struct pipe_hip_processor {
     hipStream_t stream = nullptr;  // the handle's own stream
     hipStream_t batch_stream = nullptr;  // a caller's stream the last device-resident call went to (if not `stream`)
     // StartFunc / FlushFunc order themselves after everything the handle has queued anywhere
-    int drain() const
+    int drain()
     {
-        if (batch_stream && batch_stream != stream)
-            PH_HIP(hipStreamSynchronize(batch_stream));
+        if (batch_stream && batch_stream != stream) {
+            // (the caller may have destroyed that stream since: its work is then done or gone)
+            if (hipStreamSynchronize(batch_stream) != hipSuccess)
+                (void)hipGetLastError();
+            batch_stream = nullptr;
+        }
         PH_HIP(hipStreamSynchronize(stream));
         return PIPE_HIP_OK;
     }
