@@ -84,11 +84,17 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+KERNEL_SOURCES = ("ols_math.hpp", "ols32_core.hpp", "ols32_kernel.hpp", "fir_hist.hpp", "fir_ols32.hip",
+                  "fir_ols_impl.hpp", "chain_fused.hip", "fir_ols.hip", "Makefile")
+
+
 def csrc_sha16() -> str:
-    """Identity of the kernel sources: a PMC figure is only quoted for the build it was taken on."""
+    """Identity of the sources (and build flags) of the kernels this file times: a PMC figure is only
+    quoted for the build it was taken on."""
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "pipe_amd", "csrc", "*.h*"))):
-        h.update(os.path.basename(p).encode())
+    for name in KERNEL_SOURCES:
+        p = os.path.join(ROOT, "pipe_amd", "csrc", name)
+        h.update(name.encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
