@@ -319,6 +319,19 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
             w = mul(w, T[32]);
         }
     }
+    if (S == 1) {
+        // g_i = M^(31 - i) c, c = (b1 - a1 b0, b2 - a2 b0): sample i of a segment in its zero-start end state
+        const ld b0 = coeffs[0], b1 = coeffs[1], b2 = coeffs[2], a1 = coeffs[3], a2 = coeffs[4];
+        ld g[2] = {b1 - a1 * b0, b2 - a2 * b0};
+        double *gz = h + ols::kMatGz * mm;
+        for (int i = 31; i >= 0; --i) {
+            gz[2 * i] = (double)g[0];
+            gz[2 * i + 1] = (double)g[1];
+            const ld t0 = M.m[0][0] * g[0] + M.m[0][1] * g[1], t1 = M.m[1][0] * g[0] + M.m[1][1] * g[1];
+            g[0] = t0;
+            g[1] = t1;
+        }
+    }
     I.cur_mats ^= 1;
     PH_TRY(I.upload.commit(I.mats[I.cur_mats].p, sizeof(double) * ols::kMatCount * mm, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);

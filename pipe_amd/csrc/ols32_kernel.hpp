@@ -71,7 +71,9 @@ constexpr int kMatT32 = 18;  //       (M^L)^32            : one look-back window
 constexpr int kMatTj = 19;   // [33]  (M^L)^j, j = 0..32  : a predecessor at distance j
 constexpr int kMatPk = 52;   // [32]  M^(32 (k - k0)) for k >= k0, else 1: a segment's offset in the tile
 constexpr int kMatWw = 84;   // [33]  (M^L)^(32 w), w = 0..32: w whole look-back windows
-constexpr int kMatCount = 117;
+constexpr int kMatGz = 117;  // [16]  32 x {g0, g1}: g_i = M^(31 - i) c, the weight of a segment's sample i in its
+                             //       zero-start end state (c: what one input sample adds to the state); S = 1
+constexpr int kMatCount = 133;
 constexpr int kMaxWindows = 32;  // a look-back that needs more (> 1024 tiles to the nearest P) gives up
 struct FuseArgs {
     int k0;                      // HP / 32: the lane (segment) of a tile's first output; HP % 32 == 0
@@ -268,11 +270,27 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
 #pragma unroll
         for (int c = 0; c < 32; ++c)
             xz[c] = PH_ROW(c);
-        // the two channels' chains interleaved: each step is two dependent fma per section
+        if constexpr (S == 1) {
+            // the zero-start end state is linear in the segment's samples: z = sum_i g_i x_i, two fma per
+            // sample and channel with no chain between them (the recurrence takes five, each waiting for
+            // the one before); the weights are the same for every lane: scalar loads
+            typedef const __attribute__((address_space(4))) double *const_f64;
+            const const_f64 gz = (const_f64)(fa.mats + kMatGz * 4);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            (void)biquad_step<S>(xr[c], zr, fc);
-            (void)biquad_step<S>(xz[c], zi, fc);
+            for (int c = 0; c < 32; ++c) {
+                const double g0 = gz[2 * c], g1 = gz[2 * c + 1];
+                zr[0] = __builtin_fma(g0, xr[c], zr[0]);
+                zr[1] = __builtin_fma(g1, xr[c], zr[1]);
+                zi[0] = __builtin_fma(g0, xz[c], zi[0]);
+                zi[1] = __builtin_fma(g1, xz[c], zi[1]);
+            }
+        } else {
+            // the two channels' chains interleaved: each step is two dependent fma per section
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                (void)biquad_step<S>(xr[c], zr, fc);
+                (void)biquad_step<S>(xz[c], zi, fc);
+            }
         }
     }
     // positions below HP = 32 k0 carry no output (the transform's circular wrap): the lanes that
