@@ -130,8 +130,6 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     double *xs = reinterpret_cast<double *>(smem_raw);
     constexpr int kStep = R > 1 ? R + 1 : 1;
 
-    fir_history_carry(in_base, hist_base, a.hist_new, a.frames, a.line_stride, a.H, a.C, a.lines);
-
     // staging map: lane -> (column tx = channel, row ty = frame) by shifts
     const int tx = threadIdx.x & ((1 << a.cx_log) - 1);
     const int ty = threadIdx.x >> a.cx_log;
@@ -198,13 +196,26 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         const TIn *__restrict__ src =
             in_base + (int64_t)t.line * a.line_stride + t.c0 + (ok ? tx : 0);
         const double *__restrict__ hist = hist_base + (int64_t)t.line * a.H * a.C;
+        const double *__restrict__ hsrc = hist + t.c0 + (ok ? tx : 0);
+        const bool has_hist = a.H > 0 && t.t0 - a.HP < 0;  // uniform: only a Line's first tiles
         for (int fb0 = ty; fb0 < nfr; fb0 += 8 * FY) {
             TIn v[8];
+            double hv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int64_t g = t.t0 - a.HP + fb0 + u * FY;
                 g = g < 0 ? 0 : (g > last ? last : g);
                 v[u] = src[g * a.C];
+            }
+            // the history rows are requested with the input rows (one round trip, not two:
+            // a single pipe buffer per call reads its input over PCIe)
+            if (has_hist) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int64_t gh = t.t0 - a.HP + fb0 + u * FY + a.H;
+                    gh = gh < 0 ? 0 : (gh > a.H - 1 ? a.H - 1 : gh);
+                    hv[u] = hsrc[gh * a.C];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -216,7 +227,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                     if (g >= 0)
                         w = g <= last ? loaded : 0.0;
                     else if (g >= -(int64_t)a.H)
-                        w = hist[(g + a.H) * a.C + t.c0 + tx];
+                        w = hv[u];
                     xs[tx * a.plane + pad_index<R>(f)] = w;
                 }
             }
@@ -235,6 +246,20 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         __syncthreads();  // planes of tile `id` are complete
 
         const TileCoord cur_t = tc;
+        // The history carry: new history = last H frames of (old history ++ this call's input).
+        // A Line's last tile has exactly those frames in its planes (HP >= H, and the first tile
+        // staged the old history), so it writes the other half of the double buffer from LDS --
+        // no second read of the input.
+        if (a.H > 0 && cur_t.t0 + a.TF >= a.frames) {
+            double *__restrict__ hn = a.hist_new + (int64_t)cur_t.line * a.H * a.C + cur_t.c0;
+            const int64_t f_off = a.frames - a.H - (cur_t.t0 - a.HP);  // plane frame of history row 0
+            const int n = a.H * cur_t.cg;
+            for (int e = threadIdx.x; e < n; e += kThreads) {
+                const int j = e / cur_t.cg;
+                const int c = e - j * cur_t.cg;
+                hn[(int64_t)j * a.C + c] = xs[c * a.plane + pad_index<R>((int)(f_off + j))];
+            }
+        }
         const int next = id + gridDim.x;
         fast = false;
         if (next < a.ntiles) {

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-buffer (ProcessFunc form) latency probe: one 4096x2 buffer per pipe_hip_process call.
+
+Prints, per io dtype and per register blocking R of the direct kernel (PIPE_HIP_FIR_R; "auto" = the
+library's choice): synchronous us per call, us per buffer with two buffers in flight, and the kernel's
+own duration (HIP events around the launch).  GPU box only.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from pipe_amd import processors as P  # noqa: E402
+from pipe_amd import synth  # noqa: E402
+
+
+def timed(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    F, C, N = 4096, 2, 256
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    x = synth.samples(synth.line_seed(0), 0, F * C, np.float32).reshape(F, C)
+    rs = sys.argv[1:] or ["auto"]
+    for r in rs:
+        if r == "auto":
+            os.environ.pop("PIPE_HIP_FIR_R", None)
+        else:
+            os.environ["PIPE_HIP_FIR_R"] = r
+        for dtype in (np.float32, np.float64):
+            with P.Fir(taps, F, C, dtype=dtype) as p:
+                p.start()
+                xin = x.astype(dtype)
+                best = None
+                for _ in range(3):
+                    dt = timed(lambda: p.process(xin), 400, 50)
+                    best = dt if best is None else min(best, dt)
+                p.set_profiling(True)
+                p.kernel_time(reset=True)
+                for _ in range(200):
+                    p.process(xin)
+                ms, n = p.kernel_time(reset=True)
+                p.set_profiling(False)
+                p.submit(xin)
+
+                def pipelined():
+                    p.submit(xin)
+                    p.collect()
+                best2 = None
+                for _ in range(3):
+                    dt2 = timed(pipelined, 400, 50)
+                    best2 = dt2 if best2 is None else min(best2, dt2)
+                p.collect()
+                print(json.dumps({"R": r, "io": str(np.dtype(dtype)), "sync_us": round(best * 1e6, 2),
+                                  "two_in_flight_us": round(best2 * 1e6, 2),
+                                  "kernel_us": round(ms / max(n, 1) * 1e3, 2), "launches": n}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
