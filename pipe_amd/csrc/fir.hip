@@ -102,6 +102,22 @@ __device__ __forceinline__ void fir_tap_block(double (&acc)[R], const double (&c
     }
 }
 
+// the same block with its R taps already in registers (the small-call kernel reads them from
+// LDS one block ahead)
+template <int R>
+__device__ __forceinline__ void fir_tap_block_regs(double (&acc)[R], const double (&cur)[R],
+                                                   const double (&nxt)[R], const double (&h)[R])
+{
+#pragma unroll
+    for (int kk = 0; kk < R; ++kk) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double x = (r >= kk) ? cur[r - kk] : nxt[r - kk + R];
+            acc[r] = __builtin_fma(h[kk], x, acc[r]);
+        }
+    }
+}
+
 struct TileCoord {
     int line, c0, cg;
     int64_t t0;
@@ -120,7 +136,11 @@ __device__ __forceinline__ TileCoord decode_tile(const FirArgs &a, int id)
     return t;
 }
 
-template <int R, typename TIn, typename TOut>
+// LT (R = 4 only): the variant for calls too small to fill the chip -- one pipe buffer per
+// ProcessFunc call is 8 workgroups, one wave per SIMD, nothing to hide a latency behind.  The
+// taps sit in LDS and the tap loop is software-pipelined by hand: the window block and the taps
+// of block k + 1 are requested before block k's fma run (in-order LDS reads, counted waits).
+template <int R, typename TIn, typename TOut, bool LT = false>
 __global__ void __launch_bounds__(kThreads)
 fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                   const double *__restrict__ hist_base, const double *__restrict__ taps_base,
@@ -150,7 +170,7 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     // every load is then an in-order LDS read (broadcast for the tap), so the
     // waits are counted instead of the full drain that SMEM loads would force
     const double *ltaps = reinterpret_cast<const double *>(smem_raw + a.taps_off);
-    if constexpr (kLdsTaps) {
+    if constexpr (kLdsTaps || LT) {
         double *lt = reinterpret_cast<double *>(smem_raw + a.taps_off);
         for (int k = threadIdx.x; k < a.N; k += kThreads)
             lt[k] = taps_base[k];
@@ -283,14 +303,53 @@ fir_direct_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             for (int j = 0; j < R; ++j)
                 cur[j] = w[j];
             auto tp = [&] {
-                if constexpr (kLdsTaps)
+                if constexpr (kLdsTaps || LT)
                     return ltaps;
                 else
                     return (const_f64_ptr)taps_base;
             }();
+            int kb = 0;
+            if constexpr (LT) {
+                // three window sets and three tap sets take turns (block k uses window blocks
+                // k and k + 1 and tap block k; block k + 1's operands are requested first), three
+                // blocks per trip so that no register is copied.  The last blocks and the
+                // remainder run through the plain loop below.
+                double s1[R], s2[R], h0[R], h1[R], h2[R];
+                const double *wq = w - kStep;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    s1[j] = wq[j];
+                    h0[j] = tp[j];
+                }
+                for (; kb + 5 <= a.nfull; kb += 3) {
+                    const double *tq = tp + (kb + 1) * R;
+                    wq -= kStep;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        s2[j] = wq[j];
+                        h1[j] = tq[j];
+                    }
+                    fir_tap_block_regs<R>(acc, cur, s1, h0);
+                    wq -= kStep;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        cur[j] = wq[j];
+                        h2[j] = tq[R + j];
+                    }
+                    fir_tap_block_regs<R>(acc, s1, s2, h1);
+                    wq -= kStep;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        s1[j] = wq[j];
+                        h0[j] = tq[2 * R + j];
+                    }
+                    fir_tap_block_regs<R>(acc, s2, cur, h2);
+                }
+                w -= kb * kStep;  // `cur` holds window block kb
+                tp += kb * R;
+            }
             // two tap blocks per trip so the window registers swap roles
             // instead of being copied
-            int kb = 0;
             for (; kb + 2 <= a.nfull; kb += 2) {
                 w -= kStep;
 #pragma unroll
@@ -367,6 +426,7 @@ struct Geometry {
     int R, CG, ngroups, cgp, lpc_log, cx_log, TF, HP, plane, rows, prefetch, out_slab;
     size_t out_off, taps_off, lds;
     int64_t tiles_per_line, ntiles;
+    bool lt = false;  // the small-call variant of the kernel (taps in LDS, hand-pipelined tap loop)
 };
 
 int ilog2(int v)
@@ -669,8 +729,10 @@ private:
             bool ok = geometry(4, split, frames, &g);
             while ((!ok || g.lds > 80 * 1024) && split < cfg.channels)
                 ok = geometry(4, ++split, frames, &g);
-            if (ok)
+            if (ok) {
                 *best = g;
+                best->lt = !kLdsTaps && !std::getenv("PIPE_HIP_FIR_NO_LT");
+            }
         }
         return have;
     }
@@ -681,7 +743,10 @@ private:
     {
 #define PH_FIR_LAUNCH(TI, TO, NAME)                                                                  \
     do {                                                                                             \
-        auto kfn = fir_direct_kernel<R, TI, TO>;                                                     \
+        auto kfn = fir_direct_kernel<R, TI, TO, false>;                                              \
+        if constexpr (R == 4)                                                                        \
+            if (g.lt)                                                                                \
+                kfn = fir_direct_kernel<R, TI, TO, true>;                                            \
         if (g.lds > 64 * 1024)                                                                       \
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \

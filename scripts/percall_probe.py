@@ -33,12 +33,18 @@ def main():
     x = synth.samples(synth.line_seed(0), 0, F * C, np.float32).reshape(F, C)
     rs = sys.argv[1:] or ["auto"]
     for r in rs:
-        if r == "auto":
-            os.environ.pop("PIPE_HIP_FIR_R", None)
-        else:
+        # "auto" | R | "gain" (the launch + PCIe floor) | "N<taps>" (the tap loop's share)
+        os.environ.pop("PIPE_HIP_FIR_R", None)
+        make = lambda dt: P.Fir(taps, F, C, dtype=dt)
+        if r == "gain":
+            make = lambda dt: P.Gain(0.5, F, C, dtype=dt)
+        elif r.startswith("N"):
+            tn = synth.fir_lowpass_taps(int(r[1:]), f32_rounded=True)
+            make = lambda dt: P.Fir(tn, F, C, dtype=dt)
+        elif r != "auto":
             os.environ["PIPE_HIP_FIR_R"] = r
         for dtype in (np.float32, np.float64):
-            with P.Fir(taps, F, C, dtype=dtype) as p:
+            with make(dtype) as p:
                 p.start()
                 xin = x.astype(dtype)
                 best = None

@@ -72,7 +72,7 @@ def test_gain_empty_and_mutation():
 # ------------------------------------------------------------------ FIR
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("channels", [1, 2, 3, 8])
-@pytest.mark.parametrize("ntaps", [1, 2, 17, 256, 300])
+@pytest.mark.parametrize("ntaps", [1, 2, 17, 23, 256, 300])
 def test_fir_streaming_bit_exact(dtype, channels, ntaps):
     F = 1024
     h = synth.fir_lowpass_taps(ntaps) if ntaps > 2 else np.array([0.75, -0.5][:ntaps])
