@@ -249,8 +249,11 @@ struct BiquadLdsArgs {
     int64_t frames;
     int C, S, cgroups;  // channels, sections, channel groups of <= 64 per Line
     int fb;             // frames per LDS block
+    int plane;          // doubles between two channels' planes in LDS (even, plane / 2 odd)
     double gain;
 };
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <typename TIn, typename TOut, int NS, bool GAIN>
 __global__ void __launch_bounds__(kLdsThreads)
@@ -258,7 +261,7 @@ biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                   const BiquadCoeffs q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double *xs = reinterpret_cast<double *>(smem_raw);  // [fb][cg]
+    double *xs = reinterpret_cast<double *>(smem_raw);  // [cg][plane]: one plane of frames per channel
     const int line = blockIdx.x / a.cgroups;
     const int c0 = (blockIdx.x - line * a.cgroups) * 64;
     const int cg = a.C - c0 < 64 ? a.C - c0 : 64;
@@ -319,35 +322,43 @@ biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * kLdsThreads;
                 if (e < nel)
-                    xs[e] = (double)v[u];
+                    xs[(e % cg) * a.plane + e / cg] = (double)v[u];
             }
         }
         __syncthreads();
         // ---- the recurrence, out of LDS, in place -----------------------------------
+        // The lane of a series is alone on its SIMD: every instruction it issues costs it >= 4.4
+        // cycles whatever it is (an LDS access of 16 bytes per lane ~20), so the loop holds nothing
+        // but the five float64 operations of a step and HALF an LDS instruction each way -- the
+        // series' frames are contiguous in its plane, two of them per 16-byte access, at immediate
+        // offsets from one chunk pointer.  Measured (scripts/micro/dep_fma_clock.hip): the five
+        // operations alone 21-24 cycles per step, with the two half accesses 40-43.
         if (lane_live) {
-            double *__restrict__ col = xs + tid;
+            double *__restrict__ col = xs + tid * a.plane;
             const int nch = nb / kLdsChunk;
-            double xa[kLdsChunk], xb[kLdsChunk];
+            f64x2 xa[kLdsChunk / 2], xb[kLdsChunk / 2];
             if (nch > 0) {
 #pragma unroll
-                for (int u = 0; u < kLdsChunk; ++u)
-                    xa[u] = col[u * cg];
+                for (int u = 0; u < kLdsChunk / 2; ++u)
+                    xa[u] = *reinterpret_cast<const f64x2 *>(col + 2 * u);
             }
-            // chunk k is computed while chunk k+1 is being read; the two register sets swap
-            // roles instead of being copied
-            auto run_chunk = [&](double (&x)[kLdsChunk], double (&nx)[kLdsChunk], int k) {
-                double *__restrict__ cur = col + (int64_t)k * kLdsChunk * cg;
-                if (k + 1 < nch) {
+            // chunk k is computed while chunk k+1 is being read (requested first; past the last
+            // chunk the same chunk again, so that the request stays in this basic block); the two
+            // register sets swap roles instead of being copied
+            auto run_chunk = [&](f64x2 (&x)[kLdsChunk / 2], f64x2 (&nx)[kLdsChunk / 2], int k) {
+                double *cur = col + k * kLdsChunk;
+                const double *nxt = k + 1 < nch ? cur + kLdsChunk : cur;
 #pragma unroll
-                    for (int u = 0; u < kLdsChunk; ++u)
-                        nx[u] = cur[(kLdsChunk + u) * cg];
+                for (int u = 0; u < kLdsChunk / 2; ++u)
+                    nx[u] = *reinterpret_cast<const f64x2 *>(nxt + 2 * u);
+                __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the chain
+#pragma unroll
+                for (int u = 0; u < kLdsChunk / 2; ++u) {
+                    f64x2 y;
+                    y.x = step(x[u].x);
+                    y.y = step(x[u].y);
+                    *reinterpret_cast<f64x2 *>(cur + 2 * u) = y;
                 }
-#pragma unroll
-                for (int u = 0; u < kLdsChunk; ++u)
-                    x[u] = step(x[u]);
-#pragma unroll
-                for (int u = 0; u < kLdsChunk; ++u)
-                    cur[u * cg] = x[u];
             };
             int k = 0;
             for (; k + 2 <= nch; k += 2) {
@@ -357,13 +368,13 @@ biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
             if (k < nch)
                 run_chunk(xa, xb, k);
             for (int n = nch * kLdsChunk; n < nb; ++n)
-                col[n * cg] = step(col[n * cg]);
+                col[n] = step(col[n]);
         }
         __syncthreads();
         // ---- store ------------------------------------------------------------------
         for (int e = tid; e < nel; e += kLdsThreads) {
             const int64_t g = whole ? f0 * a.C + e : (f0 + e / cg) * a.C + c0 + e % cg;
-            out[g] = (TOut)xs[e];
+            out[g] = (TOut)xs[(e % cg) * a.plane + e / cg];
         }
         __syncthreads();
     }
@@ -582,7 +593,10 @@ public:
             if (fb > frames)
                 fb = (frames + kLdsChunk - 1) / kLdsChunk * kLdsChunk;
             la.fb = (int)fb;
-            const size_t lds = sizeof(double) * (size_t)fb * (size_t)cg;
+            // planes 16-byte aligned and an odd number of 16-byte units apart: the channels'
+            // lanes read different banks
+            la.plane = (int)fb + ((fb / 2) % 2 == 0 ? 2 : 0);
+            const size_t lds = sizeof(double) * (size_t)la.plane * (size_t)cg;
             const dim3 grid((unsigned)(nl * la.cgroups));
 #define PH_BQ2(TI, TO, G)                                                                              \
     do {                                                                                               \

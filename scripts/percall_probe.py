@@ -28,16 +28,24 @@ def timed(fn, n, warm):
 
 
 def main():
-    F, C, N = 4096, 2, 256
+    F, C, N = int(os.environ.get("PROBE_F", "4096")), int(os.environ.get("PROBE_C", "2")), 256
     taps = synth.fir_lowpass_taps(N, f32_rounded=True)
     x = synth.samples(synth.line_seed(0), 0, F * C, np.float32).reshape(F, C)
     rs = sys.argv[1:] or ["auto"]
     for r in rs:
-        # "auto" | R | "gain" (the launch + PCIe floor) | "N<taps>" (the tap loop's share)
+        # "auto" | R | "gain" (the launch + PCIe floor) | "N<taps>" (the tap loop's share) | "biquad" | "biquad2" | "chain"
         os.environ.pop("PIPE_HIP_FIR_R", None)
         make = lambda dt: P.Fir(taps, F, C, dtype=dt)
         if r == "gain":
             make = lambda dt: P.Gain(0.5, F, C, dtype=dt)
+        elif r == "biquad":
+            make = lambda dt: P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=dt)
+        elif r == "biquad2":
+            make = lambda dt: P.Biquad(np.stack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(3000.0)]), F, C,
+                                       dtype=dt)
+        elif r == "chain":
+            make = lambda dt: P.Chain([P.Fir(taps, F, C, dtype=dt), P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=dt),
+                                       P.Gain(0.5, F, C, dtype=dt)])
         elif r.startswith("N"):
             tn = synth.fir_lowpass_taps(int(r[1:]), f32_rounded=True)
             make = lambda dt: P.Fir(tn, F, C, dtype=dt)
