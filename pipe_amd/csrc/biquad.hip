@@ -389,6 +389,151 @@ biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
     }
 }
 
+// Section-pipelined LDS form (2..8 sections, few Lines).  In the kernel above ONE lane runs all S
+// sections of a frame, 5 S float64 operations per step on a wave that issues one instruction per
+// >= 4.4 cycles.  Here a channel's sections sit in neighbouring lanes (8 lanes per channel) and every
+// lane runs ONE section on the same plane in place: section s works two chunks behind section s - 1,
+// reads what that lane wrote there, and overwrites it with its own output.  All communication is LDS
+// reads and writes of one wave (they retire in order: no barrier), the loop is one section's five
+// operations plus half an LDS access each way for any S, and the arithmetic of every section is the
+// oracle's, in its order: bit-exact.  Chunks are 16 frames at a stride of 18 doubles, so that the
+// lanes of a channel (two chunks = 288 bytes apart) read different banks.
+constexpr int kSpLanes = 8;                  // lanes per channel: one per section
+constexpr int kSpChannels = 64 / kSpLanes;   // channels per workgroup
+constexpr int kSpStride = kLdsChunk + 2;     // doubles from chunk to chunk in a plane
+
+__device__ __forceinline__ int sp_index(int f) { return f + 2 * (f >> 4); }
+
+template <typename TIn, typename TOut, bool GAIN>
+__global__ void __launch_bounds__(kLdsThreads)
+biquad_lds_sp_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadLdsArgs a,
+                     const BiquadCoeffs q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *xs = reinterpret_cast<double *>(smem_raw);  // [cg][plane], chunks of 16 frames 18 doubles apart
+    const int line = blockIdx.x / a.cgroups;
+    const int c0 = (blockIdx.x - line * a.cgroups) * kSpChannels;
+    const int cg = a.C - c0 < kSpChannels ? a.C - c0 : kSpChannels;
+    const int tid = threadIdx.x;
+    const int ch = tid / kSpLanes, sec = tid % kSpLanes;
+    const bool lane_live = tid < 64 && ch < cg && sec < a.S;
+    double *st = a.state + (((int64_t)line * a.C + c0 + (lane_live ? ch : 0)) * a.S + (lane_live ? sec : 0)) * 2;
+
+    double s1 = 0.0, s2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (lane_live) {
+        s1 = st[0];
+        s2 = st[1];
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxSections; ++j) {  // the lane's own section (uniform reads, per-lane select)
+        if (sec == j) {
+            b0 = q.c[j][0];
+            b1 = q.c[j][1];
+            b2 = q.c[j][2];
+            a1 = q.c[j][3];
+            a2 = q.c[j][4];
+        }
+    }
+    const double g = GAIN && sec == a.S - 1 ? a.gain : 1.0;  // y * 1.0 is y, bit for bit
+    auto step = [&](double x) -> double {
+        const double y = __builtin_fma(b0, x, s1);
+        const double t = __builtin_fma(b1, x, s2);
+        s1 = __builtin_fma(-a1, y, t);
+        const double u = b2 * x;
+        s2 = __builtin_fma(-a2, y, u);
+        if constexpr (GAIN)
+            return y * g;
+        return y;
+    };
+
+    const TIn *__restrict__ in = in_base + (int64_t)line * a.frames * a.C;
+    TOut *__restrict__ out = out_base + (int64_t)line * a.frames * a.C;
+    const bool whole = cg == a.C;
+    for (int64_t f0 = 0; f0 < a.frames; f0 += a.fb) {
+        const int nb = a.frames - f0 < a.fb ? (int)(a.frames - f0) : a.fb;
+        const int nel = nb * cg;
+        for (int e0 = tid; e0 < nel; e0 += 8 * kLdsThreads) {
+            TIn v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int e = e0 + u * kLdsThreads;
+                e = e < nel ? e : nel - 1;
+                const int64_t gi = whole ? f0 * a.C + e : (f0 + e / cg) * a.C + c0 + e % cg;
+                v[u] = in[gi];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kLdsThreads;
+                if (e < nel)
+                    xs[(e % cg) * a.plane + sp_index(e / cg)] = (double)v[u];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {  // one wave: its LDS operations retire in order
+            double *col = xs + (lane_live ? ch : 0) * a.plane;
+            const int nch = nb / kLdsChunk;
+            const int trips = nch + 2 * (a.S - 1);
+            f64x2 xa[kLdsChunk / 2], xb[kLdsChunk / 2];
+#pragma unroll
+            for (int u = 0; u < kLdsChunk / 2; ++u)
+                xa[u] = xb[u] = f64x2{0.0, 0.0};
+            if (lane_live && sec == 0 && nch > 0) {
+#pragma unroll
+                for (int u = 0; u < kLdsChunk / 2; ++u)
+                    xa[u] = *reinterpret_cast<const f64x2 *>(col + 2 * u);
+            }
+            // trip k: the lane of section s works on chunk k - 2 s (if it has one) and asks for
+            // chunk k - 2 s + 1, which section s - 1 finished in trip k - 1
+            auto run_trip = [&](f64x2 (&x)[kLdsChunk / 2], f64x2 (&nx)[kLdsChunk / 2], int k) {
+                const int kk = k - 2 * sec;
+                if (lane_live && kk >= -1 && kk < nch - 1) {
+                    const double *nxt = col + (kk + 1) * kSpStride;
+#pragma unroll
+                    for (int u = 0; u < kLdsChunk / 2; ++u)
+                        nx[u] = *reinterpret_cast<const f64x2 *>(nxt + 2 * u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (lane_live && kk >= 0 && kk < nch) {
+                    double *cur = col + kk * kSpStride;
+#pragma unroll
+                    for (int u = 0; u < kLdsChunk / 2; ++u) {
+                        f64x2 y;
+                        y.x = step(x[u].x);
+                        y.y = step(x[u].y);
+                        *reinterpret_cast<f64x2 *>(cur + 2 * u) = y;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int k = 0;
+            for (; k + 2 <= trips; k += 2) {
+                run_trip(xa, xb, k);
+                run_trip(xb, xa, k + 1);
+            }
+            if (k < trips)
+                run_trip(xa, xb, k);
+            // the frames past the last whole chunk, section after section
+            for (int j = 0; j < a.S; ++j) {
+                if (lane_live && sec == j) {
+                    for (int n = nch * kLdsChunk; n < nb; ++n)
+                        col[sp_index(n)] = step(col[sp_index(n)]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nel; e += kLdsThreads) {
+            const int64_t gi = whole ? f0 * a.C + e : (f0 + e / cg) * a.C + c0 + e % cg;
+            out[gi] = (TOut)xs[(e % cg) * a.plane + sp_index(e / cg)];
+        }
+        __syncthreads();
+    }
+    if (lane_live) {
+        st[0] = s1;
+        st[1] = s2;
+    }
+}
+
 // pass 2: per series, turn the zero-state end states z_k into the true start states s_k
 // (in place) and leave the state after the last segment in the persistent state array.
 // N = 2S states.  The z_k of kScanChunk segments are fetched together (independent loads), so
@@ -577,6 +722,44 @@ public:
 #undef PH_BQ
 #undef PH_BQ2
 #undef PH_BQ3
+        } else if (use_lds_form() && S_ >= 2 && !std::getenv("PIPE_HIP_BIQUAD_NO_SP")) {
+            // several sections: one lane per section, two chunks apart on the same LDS plane
+            BiquadLdsArgs la{};
+            la.state = a.state;
+            la.frames = frames;
+            la.C = cfg.channels;
+            la.S = S_;
+            la.cgroups = (cfg.channels + kSpChannels - 1) / kSpChannels;
+            la.gain = gain_;
+            const int cg = cfg.channels < kSpChannels ? cfg.channels : kSpChannels;
+            int64_t chunks = (60 * 1024) / (int64_t)(sizeof(double) * kSpStride * cg);
+            const int64_t need = (frames + kLdsChunk - 1) / kLdsChunk;
+            if (chunks > need)
+                chunks = need;
+            la.fb = (int)(chunks * kLdsChunk);
+            // planes an odd number of 16-byte units apart (see the S = 1 form)
+            la.plane = (int)(chunks * kSpStride) + (chunks % 2 == 0 ? 2 : 0);
+            const size_t lds = sizeof(double) * (size_t)la.plane * (size_t)cg;
+            const dim3 grid((unsigned)(nl * la.cgroups));
+#define PH_BQ(TI, TO, NAME)                                                                             \
+    do {                                                                                               \
+        if (has_gain_)                                                                                 \
+            hipLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, true>), grid, dim3(kLdsThreads), lds, s,  \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+        else                                                                                           \
+            hipLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, false>), grid, dim3(kLdsThreads), lds, s, \
+                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+        last_kernel = NAME;                                                                            \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_BQ(float, float, "biquad_lds_sp_kernel<f32,f32>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_BQ(double, double, "biquad_lds_sp_kernel<f64,f64>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_BQ(float, double, "biquad_lds_sp_kernel<f32,f64>");
+            else
+                PH_BQ(double, float, "biquad_lds_sp_kernel<f64,f32>");
+#undef PH_BQ
         } else if (use_lds_form()) {
             BiquadLdsArgs la{};
             la.state = a.state;

@@ -33,16 +33,16 @@ def main():
     x = synth.samples(synth.line_seed(0), 0, F * C, np.float32).reshape(F, C)
     rs = sys.argv[1:] or ["auto"]
     for r in rs:
-        # "auto" | R | "gain" (the launch + PCIe floor) | "N<taps>" (the tap loop's share) | "biquad" | "biquad2" | "chain"
+        # "auto" | R | "gain" (the launch + PCIe floor) | "N<taps>" (the tap loop's share) | "biquad" | "biquad<sections>" | "chain"
         os.environ.pop("PIPE_HIP_FIR_R", None)
         make = lambda dt: P.Fir(taps, F, C, dtype=dt)
         if r == "gain":
             make = lambda dt: P.Gain(0.5, F, C, dtype=dt)
         elif r == "biquad":
             make = lambda dt: P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=dt)
-        elif r == "biquad2":
-            make = lambda dt: P.Biquad(np.stack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(3000.0)]), F, C,
-                                       dtype=dt)
+        elif r.startswith("biquad"):  # biquad<sections>
+            qs = np.stack([synth.biquad_rbj_lowpass(500.0 * (j + 1)) for j in range(int(r[6:]))])
+            make = lambda dt: P.Biquad(qs, F, C, dtype=dt)
         elif r == "chain":
             make = lambda dt: P.Chain([P.Fir(taps, F, C, dtype=dt), P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=dt),
                                        P.Gain(0.5, F, C, dtype=dt)])

@@ -232,6 +232,47 @@ def test_biquad_streaming_bit_exact(dtype, channels, sections):
             pos += n
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("channels,sections,F", [(1, 3, 1024), (2, 8, 4096), (9, 5, 600), (2, 4, 8192), (17, 2, 256)])
+def test_biquad_cascade_per_buffer_bit_exact(dtype, channels, sections, F):
+    # several sections in the ProcessFunc form: one lane per section, two chunks apart on one LDS plane
+    # (biquad_lds_sp_kernel); more channels than a workgroup's 8, buffers longer than an LDS block,
+    # lengths that are not multiples of the 16-frame chunk
+    q = np.vstack([synth.biquad_rbj_lowpass(fc=300.0 * (j + 1), q=0.6 + 0.2 * j) for j in range(sections)])
+    lens = [F, 1, 0, 15, 16, 17, F, 33, F - 1, 31]
+    x = sig(7, sum(lens), channels, dtype)
+    ref = O.Biquad(q, channels)
+    with P.Biquad(q, F, channels, dtype=dtype) as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n])
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(n, channels), dtype)
+            assert np.array_equal(got, want), (pos, n)
+            pos += n
+        p.start()  # restart from silence
+        ref = O.Biquad(q, channels)
+        got = p.process(x[:F])
+        assert np.array_equal(got, expect(ref.process(x[:F].astype(np.float64)).reshape(F, channels), dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_biquad_cascade_with_gain_per_buffer_bit_exact(dtype):
+    # biquad(3 sections) -> gain as a chain: the gain rides in the last section's lane
+    F, C = 2048, 2
+    q = np.vstack([synth.biquad_rbj_lowpass(fc=500.0 * (j + 1)) for j in range(3)])
+    x = sig(9, 3 * F + 77, C, dtype)
+    rb, g = O.Biquad(q, C), 0.3125
+    with P.Chain([P.Biquad(q, F, C, dtype=dtype), P.Gain(g, F, C, dtype=dtype)]) as p:
+        p.start()
+        pos = 0
+        for n in (F, F, 77, F):
+            got = p.process(x[pos:pos + n])
+            y = rb.process(x[pos:pos + n].astype(np.float64)).reshape(n, C) * g
+            assert np.array_equal(got, expect(y, dtype)), pos
+            pos += n
+
+
 def test_biquad_many_lines_batch():
     L_, F, C, K = 70, 512, 8, 2  # 560 series: several lanes per workgroup
     q = synth.biquad_rbj_lowpass()
