@@ -40,6 +40,9 @@ def main():
             make = lambda dt: P.Gain(0.5, F, C, dtype=dt)
         elif r == "biquad":
             make = lambda dt: P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=dt)
+        elif r == "resampler":  # 44.1 -> 48 kHz, as many frames in as fill the buffer going out
+            proto = synth.resampler_proto(160, 147, 24)
+            make = lambda dt: P.Resampler(proto, 24, 160, 147, F, C, dtype=dt)
         elif r.startswith("biquad"):  # biquad<sections>
             qs = np.stack([synth.biquad_rbj_lowpass(500.0 * (j + 1)) for j in range(int(r[6:]))])
             make = lambda dt: P.Biquad(qs, F, C, dtype=dt)
@@ -55,6 +58,8 @@ def main():
             with make(dtype) as p:
                 p.start()
                 xin = x.astype(dtype)
+                if r == "resampler":
+                    xin = xin[:F * 147 // 160 - 1]
                 best = None
                 for _ in range(3):
                     dt = timed(lambda: p.process(xin), 400, 50)
