@@ -722,7 +722,7 @@ public:
 #undef PH_BQ
 #undef PH_BQ2
 #undef PH_BQ3
-        } else if (use_lds_form() && S_ >= 2 && !std::getenv("PIPE_HIP_BIQUAD_NO_SP")) {
+        } else if (use_lds_form() && S_ >= 2 && !no_sp()) {
             // several sections: one lane per section, two chunks apart on the same LDS plane
             BiquadLdsArgs la{};
             la.state = a.state;
@@ -876,6 +876,11 @@ public:
     // The LDS-staged exact kernel runs one workgroup per Line: it wins when Lines are few enough
     // that the register form cannot fill its waves anyway (always the case for the per-buffer
     // ProcessFunc form); with thousands of series the register form's 64 busy lanes per wave do.
+    static bool no_sp()  // A/B knob
+    {
+        static const bool v = std::getenv("PIPE_HIP_BIQUAD_NO_SP") != nullptr;
+        return v;
+    }
     bool use_lds_form() const
     {
         static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");

@@ -731,7 +731,8 @@ private:
                 ok = geometry(4, ++split, frames, &g);
             if (ok) {
                 *best = g;
-                best->lt = !kLdsTaps && !std::getenv("PIPE_HIP_FIR_NO_LT");
+                static const bool no_lt = std::getenv("PIPE_HIP_FIR_NO_LT") != nullptr;  // A/B knob
+                best->lt = !kLdsTaps && !no_lt;
             }
         }
         return have;
