@@ -227,7 +227,17 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     if (in_b)
         std::memcpy(g.h_in.p, in, in_b);
     if (zero_copy) {
-        PH_TRY(p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, cap, &out_frames, p->stream));
+        p->completion = g.done;
+        const int rc = p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, cap, &out_frames, p->stream);
+        const bool recorded = p->completion == nullptr;
+        p->completion = nullptr;
+        PH_TRY(rc);
+        if (recorded) {
+            g.out_frames = (int32_t)out_frames;
+            p->submit_slot ^= 1;
+            p->in_flight += 1;
+            return PIPE_HIP_OK;
+        }
     } else {
         if (in_b)
             PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));

@@ -185,6 +185,11 @@ struct pipe_hip_processor {
         int32_t out_frames = 0;
     };
     Staging stg[2];
+    // Set by submit while it queues a buffer: a stage whose LAST device operation for the call is a
+    // kernel launch may hand this event to the launch as its stop event (one API call and one
+    // barrier packet less than a hipEventRecord behind it) and clears the field; otherwise submit
+    // records the event itself.
+    hipEvent_t completion = nullptr;
     int submit_slot = 0;   // the slot the next submit fills
     int in_flight = 0;     // buffers submitted and not collected (0..2); the oldest sits in
                            // slot (submit_slot - in_flight) & 1

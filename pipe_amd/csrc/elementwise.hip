@@ -7,6 +7,8 @@
 // workgroups with a grid-stride loop.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -170,20 +172,23 @@ public:
             vec_ok = 2;
         const dim3 grid(grid_for(vec_ok ? n / kPer : n));
         PH_TRY(timer.begin(s));
+        // a ProcessFunc-form buffer: this launch is the call's last operation and signals its completion
+        hipEvent_t done = completion;
+        completion = nullptr;
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
-            hipLaunchKernelGGL((gain_kernel<float, float>), grid, dim3(kThreads), 0, s,
+            hipExtLaunchKernelGGL((gain_kernel<float, float>), grid, dim3(kThreads), 0, s, nullptr, done, 0,
                                (const float *)d_in, (float *)d_out, n, gain, vec_ok);
             last_kernel = "gain_kernel<f32,f32>";
         } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
-            hipLaunchKernelGGL((gain_kernel<double, double>), grid, dim3(kThreads), 0, s,
+            hipExtLaunchKernelGGL((gain_kernel<double, double>), grid, dim3(kThreads), 0, s, nullptr, done, 0,
                                (const double *)d_in, (double *)d_out, n, gain, vec_ok);
             last_kernel = "gain_kernel<f64,f64>";
         } else if (in_dtype == PIPE_HIP_F32) {
-            hipLaunchKernelGGL((gain_kernel<float, double>), grid, dim3(kThreads), 0, s,
+            hipExtLaunchKernelGGL((gain_kernel<float, double>), grid, dim3(kThreads), 0, s, nullptr, done, 0,
                                (const float *)d_in, (double *)d_out, n, gain, vec_ok);
             last_kernel = "gain_kernel<f32,f64>";
         } else {
-            hipLaunchKernelGGL((gain_kernel<double, float>), grid, dim3(kThreads), 0, s,
+            hipExtLaunchKernelGGL((gain_kernel<double, float>), grid, dim3(kThreads), 0, s, nullptr, done, 0,
                                (const double *)d_in, (float *)d_out, n, gain, vec_ok);
             last_kernel = "gain_kernel<f64,f32>";
         }

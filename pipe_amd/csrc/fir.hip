@@ -754,6 +754,10 @@ private:
         const dim3 grid = persistent_grid(reinterpret_cast<const void *>(kfn), g);                   \
         hipEvent_t ev_a = nullptr, ev_b = nullptr;                                                   \
         PH_TRY(timer.pair(&ev_a, &ev_b));                                                            \
+        if (!ev_b && completion && !windowed()) { /* the launch signals the buffer's completion */   \
+            ev_b = completion;                                                                       \
+            completion = nullptr;                                                                    \
+        }                                                                                            \
         hipExtLaunchKernelGGL(kfn, grid, dim3(kThreads), g.lds, s, ev_a, ev_b, 0,                    \
                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), hist, taps, a); \
         last_kernel = NAME;                                                                          \

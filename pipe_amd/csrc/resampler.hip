@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <utility>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -553,14 +555,17 @@ public:
             const int n = H * cfg.channels;
             const dim3 hg((unsigned)((n + 255) / 256), (unsigned)cfg.lines);
             double *hn = static_cast<double *>(hist_[cur_ ^ 1].p);
+            // a ProcessFunc-form buffer: the call's last launch signals its completion
+            hipEvent_t done = completion;
+            completion = nullptr;
             if (in_dtype == PIPE_HIP_F32)
-                hipLaunchKernelGGL(resample_hist_kernel<float>, hg, dim3(256), 0, s,
-                                   static_cast<const float *>(d_in), a.hist, hn, in_frames, H,
-                                   cfg.channels);
+                hipExtLaunchKernelGGL(resample_hist_kernel<float>, hg, dim3(256), 0, s, nullptr, done, 0,
+                                      static_cast<const float *>(d_in), a.hist, hn, in_frames, H,
+                                      cfg.channels);
             else
-                hipLaunchKernelGGL(resample_hist_kernel<double>, hg, dim3(256), 0, s,
-                                   static_cast<const double *>(d_in), a.hist, hn, in_frames, H,
-                                   cfg.channels);
+                hipExtLaunchKernelGGL(resample_hist_kernel<double>, hg, dim3(256), 0, s, nullptr, done, 0,
+                                      static_cast<const double *>(d_in), a.hist, hn, in_frames, H,
+                                      cfg.channels);
             PH_HIP(hipGetLastError());
             cur_ ^= 1;
         }
