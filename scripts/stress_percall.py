@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 from pipe_amd import processors as P, synth  # noqa: E402
+
+
 class _Gain:  # the oracle's gain is a function
     def __init__(self, g):
         self.g = g
