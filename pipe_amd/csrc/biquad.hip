@@ -242,7 +242,7 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
 // round trip), results go back in place, and all lanes store them coalesced.  Bit-exact like the
 // register form; the state lives in registers across blocks.
 constexpr int kLdsThreads = 256;
-constexpr int kLdsChunk = 16;
+constexpr int kLdsChunk = 32;
 
 struct BiquadLdsArgs {
     double *state;
@@ -396,13 +396,13 @@ biquad_lds_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
 // reads what that lane wrote there, and overwrites it with its own output.  All communication is LDS
 // reads and writes of one wave (they retire in order: no barrier), the loop is one section's five
 // operations plus half an LDS access each way for any S, and the arithmetic of every section is the
-// oracle's, in its order: bit-exact.  Chunks are 16 frames at a stride of 18 doubles, so that the
-// lanes of a channel (two chunks = 288 bytes apart) read different banks.
+// oracle's, in its order: bit-exact.  Chunks are kLdsChunk frames at a stride of kLdsChunk + 2 doubles, so
+// that the lanes of a channel (two chunks = 544 bytes apart) read different banks.
 constexpr int kSpLanes = 8;                  // lanes per channel: one per section
 constexpr int kSpChannels = 64 / kSpLanes;   // channels per workgroup
 constexpr int kSpStride = kLdsChunk + 2;     // doubles from chunk to chunk in a plane
 
-__device__ __forceinline__ int sp_index(int f) { return f + 2 * (f >> 4); }
+__device__ __forceinline__ int sp_index(int f) { return f + 2 * (f / kLdsChunk); }
 
 template <typename TIn, typename TOut, bool GAIN>
 __global__ void __launch_bounds__(kLdsThreads)
@@ -410,7 +410,7 @@ biquad_lds_sp_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_bas
                      const BiquadCoeffs q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double *xs = reinterpret_cast<double *>(smem_raw);  // [cg][plane], chunks of 16 frames 18 doubles apart
+    double *xs = reinterpret_cast<double *>(smem_raw);  // [cg][plane], chunks of kLdsChunk frames, kSpStride doubles apart
     const int line = blockIdx.x / a.cgroups;
     const int c0 = (blockIdx.x - line * a.cgroups) * kSpChannels;
     const int cg = a.C - c0 < kSpChannels ? a.C - c0 : kSpChannels;
