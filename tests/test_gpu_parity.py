@@ -237,9 +237,9 @@ def test_biquad_streaming_bit_exact(dtype, channels, sections):
 def test_biquad_cascade_per_buffer_bit_exact(dtype, channels, sections, F):
     # several sections in the ProcessFunc form: one lane per section, two chunks apart on one LDS plane
     # (biquad_lds_sp_kernel); more channels than a workgroup's 8, buffers longer than an LDS block,
-    # lengths that are not multiples of the 16-frame chunk
+    # lengths around the multiples of the chunk (32 frames)
     q = np.vstack([synth.biquad_rbj_lowpass(fc=300.0 * (j + 1), q=0.6 + 0.2 * j) for j in range(sections)])
-    lens = [F, 1, 0, 15, 16, 17, F, 33, F - 1, 31]
+    lens = [F, 1, 0, 15, 16, 17, F, 33, F - 1, 31, 32, 63, 64, 65]
     x = sig(7, sum(lens), channels, dtype)
     ref = O.Biquad(q, channels)
     with P.Biquad(q, F, channels, dtype=dtype) as p:
