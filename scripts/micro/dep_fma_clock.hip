@@ -132,6 +132,66 @@ __global__ void __launch_bounds__(256) bq_lds(double *out, long long *t, int n, 
     }
 }
 
+// the biquad step with its input arriving through SGPRs (s_load_dwordx16: 8 frames per scalar instruction, a
+// channel per wave, coefficients in VGPRs) and its output leaving through LDS (OUT = 0), global memory
+// (OUT = 1) or nowhere (OUT = 2)
+typedef const __attribute__((address_space(4))) double *const_f64;
+template <int OUT>
+__global__ void __launch_bounds__(256) bq_sload(double *out, long long *t, int n, const double *xg, double *yg, double b0, double b1,
+                                                double b2, double a1, double a2)
+{
+    __shared__ __attribute__((aligned(16))) double ys[4100];
+    long long c0 = 0, w0 = 0, c1 = 0, w1 = 0;
+    double s1 = 0, s2 = 0;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(a1), "+v"(a2));
+    if (threadIdx.x < 64) {
+        const_f64 xp = (const_f64)xg;
+        double xa[8], xb[8];
+        for (int u = 0; u < 8; ++u)
+            xa[u] = xp[u];
+        c0 = clock64(), w0 = wall_clock64();
+        auto step = [&](double x) {
+            const double y = __builtin_fma(b0, x, s1);
+            const double tt = __builtin_fma(b1, x, s2);
+            s1 = __builtin_fma(-a1, y, tt);
+            const double uu = b2 * x;
+            s2 = __builtin_fma(-a2, y, uu);
+            return y;
+        };
+        auto run = [&](double (&x)[8], double (&nx)[8], int k) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                nx[u] = xp[(k + 1) * 8 + u];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                f64x2 y;
+                y.x = step(x[u]);
+                y.y = step(x[u + 1]);
+                if (OUT == 0) {
+                    if (threadIdx.x == 0)
+                        *(f64x2 *)(ys + k * 8 + u) = y;
+                } else if (OUT == 1) {
+                    if (threadIdx.x == 0)
+                        *(f64x2 *)(yg + k * 8 + u) = y;
+                } else {
+                    s2 += y.x * 1e-300;
+                }
+            }
+        };
+        for (int k = 0; k + 2 <= n / 8; k += 2) {
+            run(xa, xb, k);
+            run(xb, xa, k + 1);
+        }
+        c1 = clock64(), w1 = wall_clock64();
+        out[threadIdx.x] = s1 + s2 + xa[0] + ys[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t[0] = c1 - c0;
+        t[1] = w1 - w0;
+    }
+}
+
 // 8 independent fma chains: the issue rate of float64 fma for a lone wave
 __global__ void indep(double *out, long long *t, int n, double a, double b)
 {
@@ -165,13 +225,23 @@ int main()
     hipMemset(d, 0, 256 * 8);
     hipMalloc(&t, 16);
     const int n = 4096;
-    for (int mode = 0; mode < 9; ++mode) {
+    double *xg, *yg;
+    hipMalloc(&xg, 5000 * 8);
+    hipMemset(xg, 0, 5000 * 8);
+    hipMalloc(&yg, 5000 * 8);
+    for (int mode = 0; mode < 12; ++mode) {
         double cyc = 0, wall = 0;
         const int reps = 50;
         for (int r = 0; r < reps; ++r) {
             if (mode == 0)
                 std::this_thread::sleep_for(std::chrono::microseconds(300));
-            if (mode == 5)
+            if (mode == 9)
+                hipLaunchKernelGGL((bq_sload<0>), dim3(1), dim3(256), 0, 0, d, t, n, xg, yg, 0.2, 0.4, 0.2, -0.5, 0.3);
+            else if (mode == 10)
+                hipLaunchKernelGGL((bq_sload<1>), dim3(1), dim3(256), 0, 0, d, t, n, xg, yg, 0.2, 0.4, 0.2, -0.5, 0.3);
+            else if (mode == 11)
+                hipLaunchKernelGGL((bq_sload<2>), dim3(1), dim3(256), 0, 0, d, t, n, xg, yg, 0.2, 0.4, 0.2, -0.5, 0.3);
+            else if (mode == 5)
                 hipLaunchKernelGGL((bq_lds<false, 64>), dim3(1), dim3(256), 0, 0, d, t, n, 0.2, 0.4, 0.2, -0.5, 0.3);
             else if (mode == 6)
                 hipLaunchKernelGGL((bq_lds<false, 2>), dim3(1), dim3(256), 0, 0, d, t, n, 0.2, 0.4, 0.2, -0.5, 0.3);
@@ -199,7 +269,10 @@ int main()
                            : mode == 5 ? "biquad step, wg 256, 64 live lanes, registers"
                            : mode == 6 ? "biquad step, wg 256, 2 live lanes, registers"
                            : mode == 7 ? "biquad step, wg 256, 64 live lanes, LDS in/out"
-                                       : "biquad step, wg 256, 2 live lanes, LDS in/out";
+                           : mode == 8 ? "biquad step, wg 256, 2 live lanes, LDS in/out"
+                           : mode == 9 ? "biquad step, x via s_load, y to LDS (lane 0)"
+                           : mode == 10 ? "biquad step, x via s_load, y to global (lane 0)"
+                                        : "biquad step, x via s_load, y dropped";
         std::printf("%-36s %7.2f shader cycles/step, %7.2f ns/step -> sclk %.0f MHz\n", what, cyc / reps / n,
                     wall / reps / n * 10.0, cyc / wall * 100.0);
     }
