@@ -226,18 +226,13 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     const bool zero_copy = in_b <= zero_copy_max && out_b_cap <= zero_copy_max && g.hd_in && g.hd_out;
     if (in_b)
         std::memcpy(g.h_in.p, in, in_b);
+    bool recorded = false;  // the stage's last launch carries g.done as its stop event
     if (zero_copy) {
         p->completion = g.done;
         const int rc = p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, cap, &out_frames, p->stream);
-        const bool recorded = p->completion == nullptr;
+        recorded = p->completion == nullptr;
         p->completion = nullptr;
         PH_TRY(rc);
-        if (recorded) {
-            g.out_frames = (int32_t)out_frames;
-            p->submit_slot ^= 1;
-            p->in_flight += 1;
-            return PIPE_HIP_OK;
-        }
     } else {
         if (in_b)
             PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
@@ -247,7 +242,8 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
         if (out_b)
             PH_HIP(hipMemcpyAsync(g.h_out.p, g.d_out.p, out_b, hipMemcpyDeviceToHost, p->stream));
     }
-    PH_HIP(hipEventRecord(g.done, p->stream));
+    if (!recorded)
+        PH_HIP(hipEventRecord(g.done, p->stream));
     g.out_frames = (int32_t)out_frames;
     p->submit_slot ^= 1;
     p->in_flight += 1;
