@@ -35,6 +35,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace pipehip {
@@ -741,14 +743,17 @@ public:
             la.plane = (int)(chunks * kSpStride) + (chunks % 2 == 0 ? 2 : 0);
             const size_t lds = sizeof(double) * (size_t)la.plane * (size_t)cg;
             const dim3 grid((unsigned)(nl * la.cgroups));
+            // a ProcessFunc-form buffer: this launch is the call's last operation and signals its completion
+            hipEvent_t done = completion;
+            completion = nullptr;
 #define PH_BQ(TI, TO, NAME)                                                                             \
     do {                                                                                               \
         if (has_gain_)                                                                                 \
-            hipLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, true>), grid, dim3(kLdsThreads), lds, s,  \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+            hipExtLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, true>), grid, dim3(kLdsThreads), lds, s, nullptr,  \
+                                  done, 0, static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
         else                                                                                           \
-            hipLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, false>), grid, dim3(kLdsThreads), lds, s, \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+            hipExtLaunchKernelGGL((biquad_lds_sp_kernel<TI, TO, false>), grid, dim3(kLdsThreads), lds, s, nullptr, \
+                                  done, 0, static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
         last_kernel = NAME;                                                                            \
     } while (0)
             if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
@@ -781,17 +786,19 @@ public:
             la.plane = (int)fb + ((fb / 2) % 2 == 0 ? 2 : 0);
             const size_t lds = sizeof(double) * (size_t)la.plane * (size_t)cg;
             const dim3 grid((unsigned)(nl * la.cgroups));
+            hipEvent_t done = completion;  // (see the section-pipelined form above)
+            completion = nullptr;
 #define PH_BQ2(TI, TO, G)                                                                              \
     do {                                                                                               \
         if (S_ == 1)                                                                                   \
-            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 1, G>), grid, dim3(kLdsThreads), lds, s,     \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+            hipExtLaunchKernelGGL((biquad_lds_kernel<TI, TO, 1, G>), grid, dim3(kLdsThreads), lds, s, nullptr, done, 0, \
+                                  static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);    \
         else if (S_ == 2)                                                                              \
-            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 2, G>), grid, dim3(kLdsThreads), lds, s,     \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+            hipExtLaunchKernelGGL((biquad_lds_kernel<TI, TO, 2, G>), grid, dim3(kLdsThreads), lds, s, nullptr, done, 0, \
+                                  static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);    \
         else                                                                                           \
-            hipLaunchKernelGGL((biquad_lds_kernel<TI, TO, 0, G>), grid, dim3(kLdsThreads), lds, s,     \
-                               static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);       \
+            hipExtLaunchKernelGGL((biquad_lds_kernel<TI, TO, 0, G>), grid, dim3(kLdsThreads), lds, s, nullptr, done, 0, \
+                                  static_cast<const TI *>(d_in), static_cast<TO *>(d_out), la, q_);    \
     } while (0)
 #define PH_BQ(TI, TO, NAME)            \
     do {                               \

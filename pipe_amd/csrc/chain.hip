@@ -90,7 +90,15 @@ public:
             // float64 intermediates of a chain that ends in float32 may take the FIR's
             // overlap-save form: its O(1e-16) perturbation stays far below the final ulp
             stages[i]->relaxed_f64_out = !last && out_dtype == PIPE_HIP_F32;
+            if (last) {  // the buffer's completion event may ride on the last stage's last launch
+                stages[i]->completion = completion;
+                completion = nullptr;
+            }
             const int rc = stages[i]->run(src, src_dtype, dst, dst_dtype, frames, s);
+            if (last && stages[i]->completion) {  // not taken: submit records the event itself
+                completion = stages[i]->completion;
+                stages[i]->completion = nullptr;
+            }
             if (fold)
                 biquad_set_post_gain(stages[i].get(), false, 1.0);
             PH_TRY(rc);
