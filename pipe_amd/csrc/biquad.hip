@@ -34,6 +34,7 @@
 // contract as the FIR's overlap-save form ("the one tolerance").
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -154,23 +155,43 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
             s2[s] = st[2 * s + 1];
         }
     }
+    // Runtime section count (3..8): the 40 coefficients live in VGPRs.  As kernel arguments they are
+    // 80 SGPRs, more than a wave has: the compiler spilled them into VGPR lanes and fetched every
+    // operand with v_readlane (a 3-section cascade took 7x the time of a 2-section one).
+    double cv[NS == 0 ? kMaxSections : 1][5];
+    if constexpr (NS == 0) {
+#pragma unroll
+        for (int s = 0; s < kMaxSections; ++s) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                cv[s][k] = q.c[s][k];
+                asm volatile("" : "+v"(cv[s][k]));
+            }
+        }
+    }
     auto step = [&](double x) -> double {
         double y;
         if constexpr (NS > 0) {
             y = biquad_step<NS>(x, s1, s2, q);
         } else {
+            // nested, not a flat row of guards: the sections in use are 0..S-1, so a step takes one
+            // taken branch (out of the nest) instead of one per unused section
             y = x;
-#pragma unroll
-            for (int s = 0; s < kMaxSections; ++s) {
-                if (s < a.S) {
-                    const double v = __builtin_fma(q.c[s][0], y, s1[s]);
-                    const double t = __builtin_fma(q.c[s][1], y, s2[s]);
-                    s1[s] = __builtin_fma(-q.c[s][3], v, t);
-                    const double u = q.c[s][2] * y;
-                    s2[s] = __builtin_fma(-q.c[s][4], v, u);
-                    y = v;
+            auto section = [&](auto self, auto idx) -> void {
+                constexpr int sI = decltype(idx)::value;
+                if constexpr (sI < kMaxSections) {
+                    if (sI < a.S) {
+                        const double v = __builtin_fma(cv[sI][0], y, s1[sI]);
+                        const double t = __builtin_fma(cv[sI][1], y, s2[sI]);
+                        s1[sI] = __builtin_fma(-cv[sI][3], v, t);
+                        const double u = cv[sI][2] * y;
+                        s2[sI] = __builtin_fma(-cv[sI][4], v, u);
+                        y = v;
+                        self(self, std::integral_constant<int, sI + 1>{});
+                    }
                 }
-            }
+            };
+            section(section, std::integral_constant<int, 0>{});
         }
         if constexpr (GAIN && MODE != kSegZeroState)
             y = y * a.gain;
@@ -724,7 +745,7 @@ public:
 #undef PH_BQ
 #undef PH_BQ2
 #undef PH_BQ3
-        } else if (use_lds_form() && S_ >= 2 && !no_sp()) {
+        } else if (use_sp_form()) {
             // several sections: one lane per section, two chunks apart on the same LDS plane
             BiquadLdsArgs la{};
             la.state = a.state;
@@ -888,6 +909,33 @@ public:
         static const bool v = std::getenv("PIPE_HIP_BIQUAD_NO_SP") != nullptr;
         return v;
     }
+    // The section-pipelined form: always where the LDS-staged form applies; with three or more
+    // sections also for more Lines, as long as its workgroups (one live wave each, two per CU) make
+    // at most two rounds -- 512 Lines x 8 ch x 4 sections: 163 us against 497 us for the
+    // one-lane-per-series form, whose runtime section count costs a branch nest per step.
+    bool use_sp_form() const
+    {
+        if (S_ < 2 || no_sp())
+            return false;
+        if (use_lds_form())
+            return true;
+        static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");
+        if (env)
+            return false;
+        const int64_t wgs = (int64_t)active_lines() * ((cfg.channels + kSpChannels - 1) / kSpChannels);
+        return S_ >= 3 && wgs <= 4 * (int64_t)cus();
+    }
+    int cus() const
+    {
+        if (cus_ == 0) {
+            hipDeviceProp_t prop;
+            cus_ = hipGetDeviceProperties(&prop, cfg.device) == hipSuccess && prop.multiProcessorCount > 0
+                       ? prop.multiProcessorCount
+                       : 256;
+        }
+        return cus_;
+    }
+    mutable int cus_ = 0;
     bool use_lds_form() const
     {
         static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");

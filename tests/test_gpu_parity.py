@@ -289,6 +289,31 @@ def test_biquad_many_lines_batch():
         assert np.array_equal(got[l], want), l
 
 
+@pytest.mark.parametrize("lines,channels,sections,F", [(70, 8, 3, 512), (600, 2, 8, 160), (1100, 8, 4, 96), (300, 3, 5, 200)])
+def test_biquad_cascade_many_lines_exact(lines, channels, sections, F):
+    # 3+ sections over many Lines, bit-exact forms: one lane per section while its workgroups make at
+    # most two rounds (biquad_lds_sp_kernel), beyond that one lane per series with the section count
+    # at run time (coefficients in VGPRs, nested guards)
+    K = 2
+    q = np.vstack([synth.biquad_rbj_lowpass(fc=250.0 * (j + 2), q=0.55 + 0.15 * j) for j in range(sections)])
+    x = np.stack([sig(300 + l, K * F, channels, np.float32) for l in range(lines)])
+    with P.Biquad(q, F, channels, dtype=np.float32, lines=lines, max_batch=1) as p:
+        p.start()
+        p.set_exact(True)
+        d_in = torch.from_numpy(x).cuda()
+        got = []
+        for k in range(K):  # two calls: the state carries over
+            xin = d_in[:, k * F:(k + 1) * F, :].contiguous()
+            y = torch.empty_like(xin)
+            p.process_batch(xin, y, F)
+            got.append(y)
+        torch.cuda.synchronize()
+        got = torch.cat(got, dim=1).cpu().numpy()
+    for l in sorted({0, 1, lines // 2, lines - 2, lines - 1}):
+        want = O.Biquad(q, channels).process(x[l].astype(np.float64)).reshape(K * F, channels).astype(np.float32)
+        assert np.array_equal(got[l], want), l
+
+
 # ------------------------------------------------------------------ resampler
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("up,down", [(160, 147), (147, 160), (2, 1), (1, 3)])
