@@ -472,7 +472,23 @@ public:
             if (lds <= 64 * 1024)
                 break;
         }
-        const bool tiled = lds <= 64 * 1024 && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
+        // A tap table that leaves no room for the planes in 64 KB (160 x 48 taps are 61 KB) still beats
+        // the gather kernel from a larger LDS allocation, one workgroup per CU: the largest tile that
+        // fits 144 KB.
+        constexpr size_t kBigLds = 144 * 1024;
+        if (lds > 64 * 1024 && !reg_taps) {
+            for (int cap = kOutTile; cap >= q; cap /= 2) {
+                tile_out = cap;
+                win = (int)(((int64_t)tile_out * down_ + up_ - 1) / up_) + T_ + 1;
+                plane = win + 1;
+                plane += (16 - plane % 32 + 32) % 32;
+                lds = sizeof(double) * ((size_t)T_ * up_ + (size_t)plane * cfg.channels);
+                if (lds <= kBigLds)
+                    break;
+            }
+        }
+        const bool big_lds = lds > 64 * 1024;
+        const bool tiled = lds <= (reg_taps ? (size_t)64 * 1024 : kBigLds) && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
         if (total > 0 && tiled) {
             TiledArgs t{};
             t.r = a;
@@ -497,7 +513,12 @@ public:
         case 16: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(threads), lds, s, t); break; \
         case 24: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(threads), lds, s, t); break; \
         case 32: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(threads), lds, s, t); break; \
-        default: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(threads), lds, s, t); break;  \
+        default:                                                                                         \
+            if (big_lds)                                                                                 \
+                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(resample_tiled_kernel<TI, TO, 0>),         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+            hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(threads), lds, s, t);      \
+            break;                                                                                       \
         }                                                                                                \
         last_kernel = NAME;                                                                              \
     } while (0)

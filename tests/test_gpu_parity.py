@@ -336,6 +336,38 @@ def test_resampler_streaming_bit_exact(dtype, up, down):
             pos += n
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("channels,T,up,down", [(2, 48, 160, 147), (2, 24, 320, 147), (3, 64, 147, 160)])
+def test_resampler_large_tap_table_stays_on_the_tiled_kernel(dtype, channels, T, up, down):
+    """A tap table that fills 64 KB of LDS by itself (160 phases x 48 taps) takes the tiled kernel with a
+    larger allocation instead of the gather kernel: same bits as the oracle, per buffer with a carried
+    history and as one longer device-resident call."""
+    F = 4096
+    proto = synth.resampler_proto(up, down, T)
+    lens = [F // 2, 3, 0, F // 2, 500]
+    cap = -(-F * up // down) + 1
+    x = sig(51, sum(lens) + 4 * F, channels, dtype)
+    ref = O.Resampler(proto, T, up, down, channels)
+    with P.Resampler(proto, T, up, down, F, channels, dtype=dtype, max_batch=4) as p:
+        p.start()
+        pos = 0
+        for n in lens:
+            got = p.process(x[pos:pos + n], out_cap_frames=cap)
+            want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(-1, channels), dtype)
+            assert got.shape == want.shape and np.array_equal(got, want), (pos, n)
+            pos += n
+        n = 4 * F
+        d_in = torch.from_numpy(np.ascontiguousarray(x[pos:pos + n])).cuda()
+        capb = -(-n * up // down) + 1
+        d_out = torch.empty(capb * channels, dtype=d_in.dtype, device="cuda")
+        n_out = p.resample_batch(d_in, n, d_out, capb)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_tiled_kernel"), p.kernel_name()
+        want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(-1, channels), dtype)
+        assert n_out == want.shape[0]
+        assert np.array_equal(d_out.cpu().numpy()[: n_out * channels].reshape(n_out, channels), want)
+
+
 @pytest.mark.parametrize("channels,T,up,down", [(4, 24, 160, 147), (8, 8, 3, 2), (6, 16, 2, 3), (8, 24, 147, 160)])
 def test_resampler_wide_float32_lines_take_the_pair_window_and_stay_bit_exact(channels, T, up, down):
     """float32 streams of four or more channels keep the staged window as float32 channel pairs (one LDS
