@@ -923,7 +923,8 @@ public:
         if (env)
             return false;
         const int64_t wgs = (int64_t)active_lines() * ((cfg.channels + kSpChannels - 1) / kSpChannels);
-        return S_ >= 3 && wgs <= 4 * (int64_t)cus();
+        // (two sections: the one-lane-per-series form has a compile-time variant, 172 us against 150 for one round)
+        return S_ >= 3 ? wgs <= 4 * (int64_t)cus() : wgs <= 2 * (int64_t)cus();
     }
     int cus() const
     {
