@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s through the Processor stage on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--config {1,2,3}]
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3}] [--threads]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 runs one rank per GPU, three ways to start them (the Lines each rank gets are the same):
+  * under a launcher (RANK / WORLD_SIZE / MASTER_* in the environment): this process is one rank;
+  * `python bench.py --gpus N` with no launcher: bench.py starts its own N ranks (it re-executes
+    itself under torch.distributed.run on 127.0.0.1 with a free port) -- one process per GPU;
+  * `--threads`: ONE process, one host thread + one HIP stream per GPU, no process group at all --
+    the shape of the reference's host (one Go process, a goroutine per executor: run.go:171-196,
+    merger.go:25-30; every C-ABI entry selects its handle's device itself).
 
 --config names a BASELINE.json config:
   1 (default, the config the metric is quoted on): per rank ONE Line, 2 channels, float32,
@@ -55,6 +63,8 @@ def parse():
     ap.add_argument("--taps", type=int, default=256)
     ap.add_argument("--lines", type=int, default=None, help="config 1: Lines per rank; configs 2/3: Lines in total")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--threads", action="store_true",
+                    help="N > 1 as threads of ONE process (one per GPU, no process group) instead of N processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config[2]-shape line at N = 1")
     ap.add_argument("--cpu-buffers", type=int, default=4096,
@@ -115,14 +125,64 @@ def committed_traffic(kernel: str, algorithmic_bytes: int):
     return None
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the
+    driver's launcher line would (one process per GPU, rendezvous on 127.0.0.1)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PIPE_BENCH_LAUNCH="self-spawned ranks (bench.py started torch.distributed.run)")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def run_threads(args) -> int:
+    """--threads: the N ranks are threads of this process, rank r on GPU r."""
+    import threading
+    import torch
+    from pipe_amd import shard
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not os.environ.get("PIPE_BENCH_SHARE_DEVICES"):
+        sys.exit(f"--threads --gpus {args.gpus}: only {ndev} device(s) visible "
+                 "(PIPE_BENCH_SHARE_DEVICES=1 lets ranks share devices: a rehearsal, its numbers mean nothing)")
+    sync0 = shard.ThreadSync(args.gpus)
+    results, errors = [None] * args.gpus, []
+
+    def work(r):
+        try:
+            results[r] = run_rank(args, r, args.gpus, r % ndev, sync0.for_rank(r), "threads of one process")
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, e))
+            sync0.abort()
+
+    ts = [threading.Thread(target=work, args=(r,), name=f"rank{r}") for r in range(args.gpus)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errors:
+        real = [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)] or errors
+        raise real[0][1]
+    print(json.dumps(results[0]))
+    return 0
+
+
 def main():
     args = parse()
-    import numpy as np
+    if args.threads and args.gpus > 1:
+        return run_threads(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     import torch
-
-    from pipe_amd import processors as P
-    from pipe_amd import shard, synth
-
+    from pipe_amd import shard
     rank, world, local = shard.rank_from_env()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
@@ -136,7 +196,27 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = shard.init(backend, rank, world, device=torch.device("cuda", local) if backend == "nccl" else None)
-    reduce_device = "cuda" if backend == "nccl" else "cpu"
+    sync = shard.ProcessSync(dist, "cuda" if backend == "nccl" else "cpu")
+    launch = os.environ.get("PIPE_BENCH_LAUNCH", "launcher ranks (RANK/WORLD_SIZE from the environment)"
+                            if world > 1 else "single process")
+    result = run_rank(args, rank, world, local, sync, launch)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args, rank, world, local, sync, launch):
+    """One rank's whole run; returns the bench line (meaningful on rank 0)."""
+    import numpy as np
+    import torch
+
+    from pipe_amd import processors as P
+    from pipe_amd import shard, synth
+
+    torch.cuda.set_device(local)  # (per thread: the --threads ranks each select their own)
+    dev = torch.device("cuda", local)
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -161,33 +241,34 @@ def main():
     proc.start()
 
     # synthetic input, generated on the device
-    d_in = torch.empty(n_elems, dtype=t_dtype, device="cuda")
+    d_in = torch.empty(n_elems, dtype=t_dtype, device=dev)
     d_out = torch.empty_like(d_in)
     for l, gl in enumerate(my_lines):
         P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl))
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     # The timed launches go to ONE stream named explicitly (torch's default stream has the NULL handle,
     # which the C ABI reads as "the handle's own stream" and the Python harness then brackets with
     # cross-stream waits: ~30 us of dependency latency per step that is the harness's, not the path's).
-    bench_stream = torch.cuda.Stream()
+    bench_stream = torch.cuda.Stream(device=dev)
     stream = bench_stream.cuda_stream
 
-    def timed(p, steps, warmup, d_i, d_o, fpl, barrier=False):
+    def timed(p, steps, warmup, d_i, d_o, fpl, barrier=False, call=None):
         """(elapsed s, kernel ms total, launches, kernel name) of `steps` passes after `warmup`."""
+        call = call or (lambda: p.process_batch(d_i, d_o, fpl, stream=stream))
         for _ in range(warmup):
-            p.process_batch(d_i, d_o, fpl, stream=stream)
-        torch.cuda.synchronize()
+            call()
+        torch.cuda.synchronize(dev)
         p.set_profiling(True)  # hipEvents attached to the dominant kernel's own dispatch
         p.kernel_time(reset=True)
         if barrier:
-            shard.barrier(dist)
-        torch.cuda.synchronize()
+            sync.barrier()
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
-            p.process_batch(d_i, d_o, fpl, stream=stream)
-        torch.cuda.synchronize()
+            call()
+        torch.cuda.synchronize(dev)
         if barrier:
-            shard.barrier(dist)
+            sync.barrier()
         el = time.perf_counter() - t0
         kms, n = p.kernel_time(reset=True)
         p.set_profiling(False)
@@ -205,8 +286,8 @@ def main():
 
     elapsed, kernel_ms, launches, kname = timed(proc, args.steps, args.warmup, d_in, d_out, frames_per_line,
                                                 barrier=True)
-    elapsed = shard.max_over_ranks(elapsed, dist, device=reduce_device)
-    total_samples_per_step = shard.sum_over_ranks(n_elems, dist, device=reduce_device) if world > 1 else n_elems
+    elapsed = sync.max(elapsed)
+    total_samples_per_step = int(sync.sum(n_elems)) if world > 1 else n_elems
 
     # a cheap self-check that work really happened: DC gain of the filter is 1, so the output mean
     # tracks the input mean (no oracle here: that is tests/ + smoke())
@@ -260,7 +341,7 @@ def main():
             "workload": workload, "baseline_config": cfg,
             "lines_total": total_lines, "lines_this_gpu": L, "channels": C, "buffer_frames": F,
             "buffers_per_step": K, "taps": N, "io_dtype": args.dtype,
-            "parallelism": f"line-shard x{world}", "samples": "scalar (frames x channels)",
+            "parallelism": f"line-shard x{world}", "ranks": launch, "samples": "scalar (frames x channels)",
         },
         "mframes_per_s": round(value / C, 3),
         "roofline": {
@@ -307,10 +388,10 @@ def main():
             if d_in.numel() >= n2:
                 di = d_in[:n2]
             else:  # (a --buffers smaller than this shape: its own synthetic input)
-                di = torch.empty(n2, dtype=t_dtype, device="cuda")
+                di = torch.empty(n2, dtype=t_dtype, device=dev)
                 for l in range(L2):
                     P.synth_fill(di[l * F * K2 * C:(l + 1) * F * K2 * C], synth.line_seed(l))
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(dev)
             do = torch.empty_like(di)
             _, kms2, nl2, kn2 = timed(f2, 100, 300, di, do, F * K2)
             ms2 = kms2 / max(nl2, 1)
@@ -321,6 +402,80 @@ def main():
                 "roofline_frac": round(n2 * bps / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "warmup_launches": 300, "timed_launches": 100,
             }
+            del do
+
+        def own_input(n, seed_line):
+            if d_in.numel() >= n:
+                return d_in[:n]
+            t = torch.empty(n, dtype=t_dtype, device=dev)
+            P.synth_fill(t, synth.line_seed(seed_line))
+            torch.cuda.synchronize(dev)
+            return t
+
+        # BASELINE configs[3] (SURVEY 8d "C4") at N = 1: 512 Lines x 8 ch x one 4096-frame buffer through
+        # FIR-256 -> biquad -> gain as ONE fused kernel; the same launch `--config 3` times
+        L4, C4 = 512, 8
+        n4 = L4 * F * C4
+        kw4 = dict(dtype=np_dtype, device=local, lines=L4, max_batch=1)
+        with P.Chain([P.Fir(taps, F, C4, **kw4), P.Biquad(synth.biquad_rbj_lowpass(), F, C4, **kw4),
+                      P.Gain(0.7071067811865476, F, C4, **kw4)]) as ch4:
+            ch4.start()
+            di = own_input(n4, 0)
+            do = torch.empty_like(di)
+            el4, kms4, nl4, kn4 = timed(ch4, 400, 600, di, do, F)
+            ms4 = kms4 / max(nl4, 1)
+            result["c4_chain"] = {
+                "workload": f"configs[3]: {L4} Lines x {C4} ch x {F}-frame buffer, {N}-tap FIR -> biquad -> gain, one launch per step",
+                "kernel": kn4, "avg_kernel_ms": round(ms4, 5), "ms_per_step": round(el4 / 400 * 1e3, 5),
+                "msamples_per_s": round(n4 / (el4 / 400) / 1e6, 1),
+                "algorithmic_bytes_per_launch": n4 * bps,
+                "roofline_frac": round(n4 * bps / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic": committed_traffic(kn4, n4 * bps),
+                "warmup_launches": 600, "timed_launches": 400,
+            }
+            del do
+
+        # BASELINE configs[4]: the 44.1 -> 48 kHz polyphase resampler (160/147, 24 taps per phase) over
+        # 1024 consecutive 4096 x 2 buffers per launch, and the 2-input mix ("merger fan-in": the
+        # build-defined sum) over a stream of the resampler's output size
+        T5, up5, down5, K5 = 24, 160, 147, 1024
+        n_in5 = K5 * F
+        cap5 = -(-n_in5 * up5 // down5) + 1
+        with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C, dtype=np_dtype, device=local,
+                         max_batch=K5) as rs:
+            rs.start()
+            di = own_input(n_in5 * C, 0)
+            do = torch.empty(cap5 * C, dtype=t_dtype, device=dev)
+            got = [0]
+
+            def rs_call():
+                got[0] = rs.resample_batch(di, n_in5, do, cap5, stream=stream)
+            _, kms5, nl5, kn5 = timed(rs, 200, 300, None, None, 0, call=rs_call)
+            ms5 = kms5 / max(nl5, 1)
+            by5 = (n_in5 + got[0]) * C * 4
+            c5 = {
+                "workload": f"configs[4]: 1 Line x {C} ch, {up5}/{down5} polyphase resampler ({T5} taps per phase), "
+                            f"{K5} buffers of {F} frames per launch; 2-input mix of the same stream",
+                "resampler": {"kernel": kn5, "avg_kernel_ms": round(ms5, 5), "in_frames": n_in5, "out_frames": got[0],
+                              "msamples_out_per_s": round(got[0] * C / (ms5 * 1e-3) / 1e6, 1),
+                              "algorithmic_bytes_per_launch": by5,
+                              "roofline_frac": round(by5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "traffic": committed_traffic(kn5, by5)},
+            }
+            nm = got[0] * C
+            with P.Mix(2, F, C, dtype=np_dtype, device=local, max_batch=cap5 // F + 1) as mx:
+                mx.start()
+                other = d_in[nm:2 * nm] if d_in.numel() >= 2 * nm else own_input(nm, 1)
+                mo = torch.empty(nm, dtype=t_dtype, device=dev)
+                a5 = do[:nm]
+
+                def mx_call():
+                    mx.mix_batch([a5, other], mo, got[0], stream=stream)
+                _, kmsm, nlm, knm = timed(mx, 200, 300, None, None, 0, call=mx_call)
+                msm = kmsm / max(nlm, 1)
+                c5["mix"] = {"kernel": knm, "avg_kernel_ms": round(msm, 5), "algorithmic_bytes_per_launch": 3 * nm * 4,
+                             "roofline_frac": round(3 * nm * 4 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            result["c5_resampler_mix"] = c5
             del do
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -355,12 +510,9 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an optional leg must not cost the bench line
             result["cpu_optimized"] = {"error": str(e)[:200]}
 
-    if rank == 0:
-        print(json.dumps(result))
     proc.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

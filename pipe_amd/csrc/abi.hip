@@ -279,7 +279,8 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
     }
     if (out_frames)
         *out_frames = n;
-    return PIPE_HIP_OK;
+    // (the buffer's event has been waited for: a device-side failure of its launches is known now)
+    return p->poll_error();
 }
 
 }  // namespace
@@ -394,7 +395,7 @@ int pipe_hip_start(pipe_hip_processor *p)
 
 int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count)
 {
-    if (!p || first < 0 || count < 0 || first + count > p->cfg.lines)
+    if (!p || first < 0 || count < 0 || first > p->cfg.lines || count > p->cfg.lines - first)
         return PIPE_HIP_EINVAL;
     if (p->in_flight)
         return PIPE_HIP_ESTATE;
@@ -577,7 +578,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
                         es * (size_t)in_frames[l] * (size_t)p->out_channels());
         }
     }
-    return PIPE_HIP_OK;
+    return p->poll_error();
 }
 
 int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
@@ -629,7 +630,7 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
                                    p->stream));
     }
     PH_HIP(hipStreamSynchronize(p->stream));
-    return PIPE_HIP_OK;
+    return p->poll_error();
 }
 
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,

@@ -526,6 +526,12 @@ biquad_lds_sp_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_bas
                         *reinterpret_cast<f64x2 *>(cur + 2 * u) = y;
                     }
                 }
+                // What this lane stored is read by the NEXT section's lane in the next trip: a
+                // cross-lane dependency the compiler cannot see (per lane the addresses differ).
+                // The wavefront-scope fence makes the order part of the program (it emits no
+                // instruction: one wave's LDS operations retire in order); the scheduling barrier
+                // keeps the requests ahead of the chain.
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_sched_barrier(0);
             };
             int k = 0;
@@ -541,6 +547,7 @@ biquad_lds_sp_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_bas
                     for (int n = nch * kLdsChunk; n < nb; ++n)
                         col[sp_index(n)] = step(col[sp_index(n)]);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // section j + 1 reads what section j stored
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -132,7 +132,7 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
-    int poll_error() override { return fused_ ? fused_->poll_error(stream) : PIPE_HIP_OK; }
+    int poll_error() override { return fused_ ? fused_->poll_error() : PIPE_HIP_OK; }
     int set_stage_param(int32_t stage, int32_t param, const double *values, int32_t count) override
     {
         if (stage < 0 || (size_t)stage >= stages.size())
@@ -143,7 +143,7 @@ public:
 private:
     bool fusable(const void *d_in, int in_dtype, const void *d_out, int out_dtype, int64_t frames) const
     {
-        if (!fused::Plan::enabled() || windowed() || frames <= 0)
+        if (!fused::Plan::enabled() || windowed() || frames <= 0 || !fused::Plan::launchable())
             return false;
         if (stages.size() != 2 && stages.size() != 3)
             return false;

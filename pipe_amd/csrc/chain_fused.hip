@@ -228,7 +228,9 @@ __global__ void chain_state_export_kernel(double *__restrict__ state, const unsi
 }  // namespace
 
 struct Plan::Impl {
-    DevBuf rec, mats[2], seg_state, own, err, prof;
+    DevBuf rec, mats[2], seg_state, own, prof;
+    PinnedBuf err;            // host-resident, device-visible: the host reads it after any synchronisation
+    int *err_dev = nullptr;   // the kernel's alias of it
     int own_series = 0;       // channel pairs the slots were sized for
     bool in_slots = false;    // the cascade's state lives in the slots (else in the biquad stage's array)
     double *bq_state = nullptr;
@@ -294,7 +296,10 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
         PH_TRY(I.mats[0].alloc(bytes));
         PH_TRY(I.mats[1].alloc(bytes));
         PH_TRY(I.err.alloc(sizeof(int)));
-        PH_HIP(hipMemsetAsync(I.err.p, 0, sizeof(int), s));
+        *static_cast<volatile int *>(I.err.p) = 0;
+        void *alias = nullptr;
+        PH_HIP(hipHostGetDevicePointer(&alias, I.err.p, 0));
+        I.err_dev = static_cast<int *>(alias);
     }
     void *host = nullptr;
     PH_TRY(I.upload.stage(bytes, &host));
@@ -340,22 +345,58 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     return PIPE_HIP_OK;
 }
 
-int Plan::poll_error(hipStream_t s)
+// Precondition: the stream the last launch went to has been synchronised (every caller has just
+// waited for the buffer it hands back).  The flag lives in pinned host memory, so this is a plain
+// read -- cheap enough for every synchronous entry point, not only FlushFunc.
+int Plan::poll_error()
 {
     Impl &I = *impl_;
     if (!I.err.p || I.err_checked)
         return PIPE_HIP_OK;
-    if (I.last_stream)
-        s = I.last_stream;  // the stream the last launch went to
-    int e = 0;
-    PH_HIP(hipMemcpyAsync(&e, I.err.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    PH_HIP(hipStreamSynchronize(s));
+    volatile int *e = static_cast<volatile int *>(I.err.p);
     I.err_checked = true;
-    if (e != 0) {
-        PH_HIP(hipMemsetAsync(I.err.p, 0, sizeof(int), s));
+    if (*e != 0) {
+        *e = 0;
         return PIPE_HIP_EHIP;
     }
     return PIPE_HIP_OK;
+}
+
+// Every workgroup of a fused launch must be resident at once (tiles wait for their predecessors):
+// one 512-thread workgroup with this much LDS has to fit a CU.  Asked once per kernel form; a
+// device (or a runtime LDS carve-out) where it does not fit takes the staged chain instead.
+template <int S, bool GENERAL, bool LOCAL>
+static bool form_fits()
+{
+    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
+    const size_t lds = sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) +
+                       sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
+                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing + 4 * sizeof(unsigned) : 0);
+    int per_cu = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kfn), kWaves32 * 64, lds) !=
+            hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return per_cu >= 1;
+}
+
+bool Plan::launchable()
+{
+    static std::mutex mu;
+    static int known[64] = {};  // per device: 0 = not asked, 1 = fits, 2 = does not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    dev &= 63;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[dev])
+        known[dev] = form_fits<1, true, false>() && form_fits<1, false, true>() && form_fits<1, false, false>() ? 1 : 2;
+    return known[dev] == 1;
 }
 
 // the cascade's state back into the biquad stage's own array: before anything but the fused
@@ -512,7 +553,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         PH_TRY(I.seg_state.alloc(seg_bytes));
     fa.seg_state = static_cast<double *>(I.seg_state.p);
     fa.mats = static_cast<const double *>(I.mats[I.cur_mats].p);
-    fa.err = static_cast<int *>(I.err.p);
+    fa.err = I.err_dev;
 #ifdef PH_FUSE_PROF
     if (!I.prof.p)
         PH_TRY(I.prof.alloc(sizeof(unsigned long long) * ols::kFuseProfPhases * kWaves32 * 4096));

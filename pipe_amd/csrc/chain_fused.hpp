@@ -29,8 +29,11 @@ public:
     int run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_processor::BiquadFuseView &bq, bool has_gain,
             double gain, const void *d_in, void *d_out, int64_t frames, int channels, int lines, hipStream_t s,
             KernelTimer *timer, const char **kernel_name);
-    // EHIP if a launch since the last poll gave up waiting for a predecessor tile
-    int poll_error(hipStream_t s);
+    // the fused kernel's workgroup (512 threads + its LDS) fits a CU of the current device
+    static bool launchable();
+    // EHIP if a launch since the last poll gave up waiting for a predecessor tile.  The caller has
+    // synchronised the launch stream; this is a read of a pinned flag.
+    int poll_error();
     // While a chain stays fused the cascade's state lives in the plan (two tagged slots per channel
     // pair: the last tile of a launch writes it, the first tiles of the next read it, no kernel in
     // between).  export_state() moves it back into the biquad stage's own array -- before the

@@ -221,18 +221,18 @@ public:
             vec_ok = vec_ok && aligned_to(d_ins[i], dtype_size(cfg.dtype) * kPer);
         }
         const dim3 grid(grid_for(vec_ok ? n / kPer : n));
-        PH_TRY(timer.begin(s));
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        PH_TRY(timer.pair(&ev_a, &ev_b));
         if (cfg.dtype == PIPE_HIP_F32) {
-            hipLaunchKernelGGL(mix_kernel<float>, grid, dim3(kThreads), 0, s, ptrs, n_inputs,
+            hipExtLaunchKernelGGL(mix_kernel<float>, grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs,
                                (float *)d_out, n, vec_ok);
             last_kernel = "mix_kernel<f32>";
         } else {
-            hipLaunchKernelGGL(mix_kernel<double>, grid, dim3(kThreads), 0, s, ptrs, n_inputs,
+            hipExtLaunchKernelGGL(mix_kernel<double>, grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs,
                                (double *)d_out, n, vec_ok);
             last_kernel = "mix_kernel<f64>";
         }
         PH_HIP(hipGetLastError());
-        PH_TRY(timer.end(s));
         return PIPE_HIP_OK;
     }
 };

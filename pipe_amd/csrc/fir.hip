@@ -475,6 +475,11 @@ __global__ void fir_hist_convert_kernel(const TSrc *__restrict__ src, TDst *__re
 
 class Fir final : public pipe_hip_processor {
 public:
+    ~Fir() override
+    {
+        if (taps_uploaded_)
+            (void)hipEventDestroy(taps_uploaded_);
+    }
     int init(const double *taps, int32_t ntaps)
     {
         N_ = ntaps;
@@ -533,10 +538,26 @@ public:
         PH_TRY(upload_.stage(bytes, &host));
         std::memcpy(host, values, bytes);
         const int nxt = cur_taps_ ^ 1;
-        PH_TRY(upload_.commit(taps_[nxt].p, bytes, last_stream()));
+        // The caller's stream of the last device-resident call may be gone by now (its owner
+        // destroyed it): ask before queueing on it, and use the handle's own stream if so.
+        if (last_stream_ && last_stream_ != stream) {
+            const hipError_t q = hipStreamQuery(last_stream_);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                last_stream_ = nullptr;
+            }
+        }
+        hipStream_t us = last_stream();
+        PH_TRY(upload_.commit(taps_[nxt].p, bytes, us));
         cur_taps_ = nxt;
         if (ols_)
-            PH_TRY(ols_->set_taps(values, last_stream()));
+            PH_TRY(ols_->set_taps(values, us));
+        // a launch that goes to ANOTHER stream next waits for this upload (run / fuse_view_fir)
+        if (!taps_uploaded_)
+            PH_HIP(hipEventCreateWithFlags(&taps_uploaded_, hipEventDisableTiming));
+        PH_HIP(hipEventRecord(taps_uploaded_, us));
+        upload_stream_ = us;
+        upload_pending_ = true;
         return PIPE_HIP_OK;
     }
 
@@ -545,6 +566,7 @@ public:
     {
         if (frames <= 0)
             return PIPE_HIP_OK;
+        PH_TRY(order_after_upload(s));
         last_stream_ = s;
         PH_TRY(ensure_hist_type(false, s));  // these kernels read a float64 history
         // a window of Lines (pipe_hip_process_lines with ragged lengths): the per-Line history
@@ -596,7 +618,8 @@ public:
     {
         if (!ols_ || windowed())
             return false;
-        if (prepare && ensure_hist_type(true, s) != PIPE_HIP_OK)  // the fused kernel: float32 history
+        if (prepare && (order_after_upload(s) != PIPE_HIP_OK ||
+                        ensure_hist_type(true, s) != PIPE_HIP_OK))  // the fused kernel: float32 history
             return false;
         v->hist = hist_[cur_hist_].p;
         v->hist_new = hist_next();
@@ -806,6 +829,19 @@ private:
     }
 
     hipStream_t last_stream() const { return last_stream_ ? last_stream_ : stream; }
+    // a tap upload queued on one stream, the next launch on another: the launch waits for it
+    int order_after_upload(hipStream_t s)
+    {
+        if (upload_pending_) {
+            if (s != upload_stream_)
+                PH_HIP(hipStreamWaitEvent(s, taps_uploaded_, 0));
+            upload_pending_ = false;
+        }
+        return PIPE_HIP_OK;
+    }
+    hipEvent_t taps_uploaded_ = nullptr;
+    hipStream_t upload_stream_ = nullptr;
+    bool upload_pending_ = false;
 
     int N_ = 0, H_ = 0;
     int cus_ = 256;

@@ -188,15 +188,37 @@ public:
     }
     const std::shared_ptr<Handle> &handle() const { return h_; }
 
-    // a slot's StartFunc zeroes THAT Line's state only: the Lines of a group start together
-    // before the first pass (run.go:76-85), but a Line added to a running pipe (Pipe.AddLine) must
-    // not reset the others
-    error start(int slot) { return StatusError(pipe_hip_start_lines(h_->get(), slot, 1), "start"); }
+    // A slot's StartFunc.  The Lines of a group start together before the first pass
+    // (run.go:76-85): the first of them starts the WHOLE handle once (one drain and one memset per
+    // stage, not `lines` of them) and the others find it started.  A Line that joins a group that
+    // has run a pass since (Pipe.AddLine) must not reset the others: its slot alone starts from
+    // silence (pipe_hip_start_lines).
+    error start(int slot)
+    {
+        int st = PIPE_HIP_OK;
+        if (live_ == 0) {  // no Line of the group is live
+            st = pipe_hip_start(h_->get());
+            dirty_ = false;
+        } else if (dirty_) {
+            st = pipe_hip_start_lines(h_->get(), slot, 1);
+        }
+        if (st == PIPE_HIP_OK)
+            ++live_;  // (a failed StartFunc gets no FlushFunc: run.go:54-62)
+        return StatusError(st, "start");
+    }
+    // a Line's FlushFunc (its stream ended, or the pipe stops): the other Lines keep running
+    error flush()
+    {
+        if (live_ > 0)
+            --live_;
+        return StatusError(pipe_hip_flush(h_->get()), "flush");
+    }
 
     error ProcessLines(const std::vector<const signal::Floating *> &ins, const std::vector<signal::Floating *> &outs,
                        std::vector<int> *processed) override
     {
         const size_t n = (size_t)lines_;
+        dirty_ = true;
         in_ptr_.assign(n, nullptr);
         out_ptr_.assign(n, nullptr);
         frames_.assign(n, 0);
@@ -230,6 +252,8 @@ private:
     Options o_;
     std::shared_ptr<Handle> h_;
     int bufferSize_ = 0, channels_ = 0;
+    int live_ = 0;        // slots started and not flushed
+    bool dirty_ = false;  // a pass has run since the whole handle was last started
     std::vector<const void *> in_ptr_;
     std::vector<void *> out_ptr_;
     std::vector<int32_t> frames_, written_;
@@ -261,9 +285,7 @@ std::vector<ProcessorAllocatorFunc> BatchedChain(std::vector<StageSpec> stages, 
             out->Batch = group;
             out->BatchSlot = slot;
             out->StartFunc = [group, slot](const Context &) -> error { return group->start(slot); };
-            out->FlushFunc = [group](const Context &) -> error {
-                return StatusError(pipe_hip_flush(group->handle()->get()), "flush");
-            };
+            out->FlushFunc = [group](const Context &) -> error { return group->flush(); };
             out->ProcessFunc = [](const signal::Floating &, signal::Floating &, int *) -> error {
                 return NewError("batched processor: run the Lines with pipe::RunBatched");
             };

@@ -504,20 +504,22 @@ public:
             const int64_t slots = (reg_taps ? 4 : 3) * 256;  // workgroups resident per CU (registers bound them: 12 waves)
             const int64_t per = (ntiles + slots - 1) / slots;
             const dim3 grid((unsigned)((ntiles + per - 1) / per));
-            PH_TRY(timer.begin(s));
+            // events attached to the kernel's own dispatch (what rocprofv3 reports)
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            PH_TRY(timer.pair(&ev_a, &ev_b));
 #define PH_RS(TI, TO, NAME)                                                                              \
     do {                                                                                                 \
         switch (reg_taps ? T_ : 0) {                                                                     \
-        case 8: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 8>), grid, dim3(threads), lds, s, t); break;   \
-        case 12: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 12>), grid, dim3(threads), lds, s, t); break; \
-        case 16: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(threads), lds, s, t); break; \
-        case 24: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(threads), lds, s, t); break; \
-        case 32: hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(threads), lds, s, t); break; \
+        case 8: hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 8>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break;   \
+        case 12: hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 12>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        case 16: hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 16>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        case 24: hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 24>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        case 32: hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 32>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
         default:                                                                                         \
             if (big_lds)                                                                                 \
                 PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(resample_tiled_kernel<TI, TO, 0>),         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-            hipLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(threads), lds, s, t);      \
+            hipExtLaunchKernelGGL((resample_tiled_kernel<TI, TO, 0>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t);      \
             break;                                                                                       \
         }                                                                                                \
         last_kernel = NAME;                                                                              \
@@ -525,11 +527,11 @@ public:
 #define PH_RS32(TO, NAME)                                                                                         \
     do {                                                                                                          \
         switch (T_) {                                                                                             \
-        case 8: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 8, true>), grid, dim3(threads), lds, s, t); break;   \
-        case 12: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 12, true>), grid, dim3(threads), lds, s, t); break; \
-        case 16: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 16, true>), grid, dim3(threads), lds, s, t); break; \
-        case 24: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 24, true>), grid, dim3(threads), lds, s, t); break; \
-        default: hipLaunchKernelGGL((resample_tiled_kernel<float, TO, 32, true>), grid, dim3(threads), lds, s, t); break; \
+        case 8: hipExtLaunchKernelGGL((resample_tiled_kernel<float, TO, 8, true>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break;   \
+        case 12: hipExtLaunchKernelGGL((resample_tiled_kernel<float, TO, 12, true>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        case 16: hipExtLaunchKernelGGL((resample_tiled_kernel<float, TO, 16, true>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        case 24: hipExtLaunchKernelGGL((resample_tiled_kernel<float, TO, 24, true>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
+        default: hipExtLaunchKernelGGL((resample_tiled_kernel<float, TO, 32, true>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t); break; \
         }                                                                                                         \
         last_kernel = NAME;                                                                                       \
     } while (0)
@@ -548,7 +550,6 @@ public:
 #undef PH_RS32
 #undef PH_RS
             PH_HIP(hipGetLastError());
-            PH_TRY(timer.end(s));
         } else if (total > 0) {
             int64_t b = (total + kThreads - 1) / kThreads;
             if (b > 4096)

@@ -72,6 +72,59 @@ def sum_over_ranks(value: float, dist, device: Optional[str] = None) -> float:
     return float(t.item())
 
 
+class ProcessSync:
+    """The ranks are PROCESSES (one per GPU): barrier and reductions through torch.distributed
+    (RCCL on GPUs, gloo on CPU); with dist None a single process."""
+
+    def __init__(self, dist, device: Optional[str] = None):
+        self.dist, self.device = dist, device
+
+    def barrier(self) -> None:
+        barrier(self.dist)
+
+    def max(self, value: float) -> float:
+        return max_over_ranks(value, self.dist, self.device)
+
+    def sum(self, value: float) -> float:
+        return sum_over_ranks(value, self.dist, self.device)
+
+
+class ThreadSync:
+    """The ranks are THREADS of one process, one per GPU -- what a Go host is: one process, a
+    goroutine per Line executor (run.go:171-196, merger.go:25-30), every C-ABI entry selecting its
+    handle's device itself.  No process group: a threading.Barrier and a shared slot per rank."""
+
+    def __init__(self, world: int, shared=None):
+        import threading
+        if shared is None:
+            shared = {"barrier": threading.Barrier(world), "slots": [0.0] * world}
+        self.world, self.shared, self.rank = world, shared, 0
+
+    def for_rank(self, rank: int) -> "ThreadSync":
+        t = ThreadSync(self.world, self.shared)
+        t.rank = rank
+        return t
+
+    def barrier(self) -> None:
+        self.shared["barrier"].wait()
+
+    def abort(self) -> None:  # a rank failed: the others must not wait for it for ever
+        self.shared["barrier"].abort()
+
+    def _gather(self, value: float):
+        self.shared["slots"][self.rank] = float(value)
+        self.barrier()
+        vals = list(self.shared["slots"])
+        self.barrier()  # nobody overwrites a slot before everybody has read it
+        return vals
+
+    def max(self, value: float) -> float:
+        return max(self._gather(value))
+
+    def sum(self, value: float) -> float:
+        return float(sum(self._gather(value)))
+
+
 def aggregate_throughput(samples_per_rank_step: int, steps: int, world: int, max_elapsed_s: float) -> float:
     """Whole-job Msamples/s: all ranks' samples over the slowest rank's time."""
     return samples_per_rank_step * world * steps / max_elapsed_s / 1e6

@@ -10,9 +10,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
+def run_bench(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=900, env=e)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # exactly ONE JSON line
@@ -37,6 +39,17 @@ def test_default_line_has_every_contract_field():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Msamples/s" and c["sample"]
     assert d["bit_exact_form"]["kernel"] == "fir_direct_kernel"
+    # BASELINE configs[3] and configs[4] ride in the same line (what the driver records)
+    c4 = d["c4_chain"]
+    assert c4["kernel"].startswith("chain_fused_kernel") and c4["algorithmic_bytes_per_launch"] == 8 * 512 * 4096 * 8
+    assert 0 < c4["avg_kernel_ms"] <= c4["ms_per_step"] * 1.05
+    assert abs(c4["roofline_frac"] - c4["algorithmic_bytes_per_launch"] / (c4["avg_kernel_ms"] * 1e-3) / 8e12) < 1e-3
+    c5 = d["c5_resampler_mix"]
+    r5 = c5["resampler"]
+    assert r5["kernel"].startswith("resample_tiled_kernel") and r5["in_frames"] == 1024 * 4096
+    assert r5["out_frames"] in (-(-1024 * 4096 * 160 // 147), 1024 * 4096 * 160 // 147)
+    assert r5["algorithmic_bytes_per_launch"] == (r5["in_frames"] + r5["out_frames"]) * 2 * 4
+    assert c5["mix"]["kernel"] == "mix_kernel<f32>" and 0 < c5["mix"]["roofline_frac"] < 1.0
 
 
 def test_config3_line_names_the_fused_chain():
@@ -44,3 +57,30 @@ def test_config3_line_names_the_fused_chain():
     assert "configs[3]" in d["config"]["workload"] and d["scaling"] == "strong"
     assert d["roofline"]["kernel"].startswith("chain_fused_kernel") and d["config"]["lines_total"] == 512
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 512 * 4096 * 8
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment: two processes, Line i on
+    rank i mod 2, ONE line with n_gpus 2 and both ranks' samples in `value` (the 1-GPU box shares the
+    device between the ranks over gloo: a rehearsal of the launch / barrier / reduce logic, no scaling
+    figure -- run.go:112-132 Lines share nothing, merger.go:25-30 one executor per goroutine)."""
+    d = run_bench("--gpus", "2", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                  env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
+    assert "self-spawned" in d["config"]["ranks"] and d["scaling"] == "strong"
+    # value counts BOTH ranks' samples: 512 Lines x 4096 x 8 per step over the slowest rank's time
+    assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 4096 * 8) - 1.0) < 0.02
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 4096 * 8   # one rank's launch
+
+
+def test_threads_mode_is_one_process_with_a_thread_per_rank():
+    """--threads: the ranks are threads of ONE process (the shape of a Go host), no process group."""
+    d = run_bench("--gpus", "2", "--threads", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                  env={"PIPE_BENCH_SHARE_DEVICES": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
+    assert "threads" in d["config"]["ranks"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 4096 * 8) - 1.0) < 0.02
+    w = run_bench("--gpus", "2", "--threads", "--steps", "3", "--warmup", "1", "--buffers", "2048", "--no-cpu-baseline",
+                  env={"PIPE_BENCH_SHARE_DEVICES": "1"})
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["lines_total"] == 2
+    assert abs(w["value"] * w["ms_per_step"] * 1e3 / (2 * 2048 * 4096 * 2) - 1.0) < 0.02

@@ -423,6 +423,78 @@ def test_resampler_config5_capacity_contract():
         assert got.shape == (4096, C) and np.array_equal(got, want.astype(np.float32))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_config5_composed_stream_resampler_into_two_input_mix(dtype):
+    """BASELINE configs[4] composed as a stream: two 44.1 kHz sources of 3763-frame buffers (the
+    largest whose 160/147 output fits ProcessFunc's 4096-frame out), each through its
+    own polyphase resampler, the two 48 kHz streams summed by the 2-input mix ("merger fan-in":
+    build-defined, SURVEY F2).  Every buffer of the mixed stream against the oracle's, bit for bit;
+    buffers between the stages carry the handle's dtype, so float32 rounds once per stage."""
+    T, up, down, F, C, FIN = 24, 160, 147, 4096, 2, 3763
+    proto = synth.resampler_proto(up, down, T)
+    lens = [FIN] * 9 + [1000, 0, 77]              # short reads and an empty one near the end
+    xa, xb = sig(61, sum(lens), C, dtype), sig(62, sum(lens), C, dtype)
+    ra, rb = O.Resampler(proto, T, up, down, C), O.Resampler(proto, T, up, down, C)
+    with P.Resampler(proto, T, up, down, F, C, dtype=dtype) as pa, P.Resampler(proto, T, up, down, F, C, dtype=dtype) as pb, \
+            P.Mix(2, F, C, dtype=dtype) as mx:
+        pa.start(); pb.start(); mx.start()
+        pos, total = 0, 0
+        for n in lens:
+            ya = pa.process(xa[pos:pos + n], out_cap_frames=F)
+            yb = pb.process(xb[pos:pos + n], out_cap_frames=F)
+            assert ya.shape == yb.shape and ya.shape[0] <= F
+            wa = expect(ra.process(xa[pos:pos + n].astype(np.float64)).reshape(-1, C), dtype)
+            wb = expect(rb.process(xb[pos:pos + n].astype(np.float64)).reshape(-1, C), dtype)
+            assert np.array_equal(ya, wa) and np.array_equal(yb, wb), pos
+            if ya.shape[0]:
+                got = mx.process([ya, yb])
+                want = expect(O.mix([wa.astype(np.float64), wb.astype(np.float64)]), dtype)
+                assert np.array_equal(got, want), pos
+            total += ya.shape[0]
+            pos += n
+        assert total == -(-sum(lens) * up // down)   # ceil: every input frame accounted for
+
+
+def test_resample_batch_at_the_bench_shape_windows_against_oracle():
+    """The launch bench.py times for configs[4]: 1024 buffers of 4096 x 2 float32 in ONE
+    resample_batch call (4.19 M frames in, 4.56 M out), followed by the 2-input mix on the device.
+    The oracle runs the whole stream (it is a 24-tap filter: seconds); start, middle and end windows
+    and a strided sample of the rest are compared bit for bit."""
+    T, up, down, F, C, K = 24, 160, 147, 4096, 2, 1024
+    proto = synth.resampler_proto(up, down, T)
+    n_in = K * F
+    cap = -(-n_in * up // down) + 1
+    d_in = torch.empty(n_in * C, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(0))
+    d_out = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
+    with P.Resampler(proto, T, up, down, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        n_out = p.resample_batch(d_in, n_in, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_tiled_kernel")
+        # a second launch continues the stream (what the bench's timed loop does)
+        d_out2 = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
+        n_out2 = p.resample_batch(d_in, n_in, d_out2, cap)
+        torch.cuda.synchronize()
+    x = synth.samples(synth.line_seed(0), 0, n_in * C).reshape(n_in, C)
+    ref = O.Resampler(proto, T, up, down, C)
+    want = ref.process(x).reshape(-1, C).astype(np.float32)
+    want2 = ref.process(x).reshape(-1, C).astype(np.float32)
+    assert n_out == want.shape[0] and n_out2 == want2.shape[0] and n_out + n_out2 == -(-2 * n_in * up // down)
+    got = d_out.cpu().numpy()[: n_out * C].reshape(n_out, C)
+    got2 = d_out2.cpu().numpy()[: n_out2 * C].reshape(n_out2, C)
+    assert np.array_equal(got, want) and np.array_equal(got2, want2)
+    # the mix of the two launches' outputs, on the device
+    m = min(n_out, n_out2)
+    with P.Mix(2, F, C, dtype=np.float32, max_batch=m // F + 1) as mx:
+        mx.start()
+        mo = torch.empty(m * C, dtype=torch.float32, device="cuda")
+        mx.mix_batch([d_out[: m * C], d_out2[: m * C]], mo, m)
+        torch.cuda.synchronize()
+    wm = (want[:m].astype(np.float64) + want2[:m].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(mo.cpu().numpy().reshape(m, C), wm)
+
+
 # ------------------------------------------------------------------ mix, chain
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n_in", [2, 3])

@@ -73,3 +73,52 @@ def test_two_rank_sharding_and_timing(tmp_path):
     got.update(zip(shard.line_indices(1, 2, 5), r1[3:]))
     assert got == want
     assert shard.aggregate_throughput(1000, 10, 2, 0.5) == 1000 * 2 * 10 / 0.5 / 1e6
+
+
+def test_thread_ranks_barrier_and_reductions():
+    """bench.py --threads: the ranks are threads of one process (the reference's host shape:
+    run.go:171-196, one goroutine per executor); same partition, barrier and reductions."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from pipe_amd import shard
+    world = 3
+    root = shard.ThreadSync(world)
+    out = [None] * world
+
+    def work(r):
+        s = root.for_rank(r)
+        mine, total, kind = shard.plan_lines(3, r, world)
+        s.barrier()
+        time.sleep(0.02 * (r + 1))
+        s.barrier()
+        out[r] = (s.max(0.1 * (r + 1)), s.sum(len(mine)), s.max(float(r)), total, kind)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert all(o is not None for o in out)
+    for o in out:
+        assert abs(o[0] - 0.3) < 1e-12 and o[1] == 512 and o[2] == 2.0 and o[3] == 512 and o[4] == "strong"
+
+
+def test_thread_ranks_abort_releases_the_others():
+    import threading
+    sys.path.insert(0, ROOT)
+    from pipe_amd import shard
+    root = shard.ThreadSync(2)
+    seen = []
+
+    def waiter():
+        try:
+            root.for_rank(0).barrier()
+        except threading.BrokenBarrierError:
+            seen.append("released")
+
+    t = threading.Thread(target=waiter)
+    t.start()
+    time.sleep(0.05)
+    root.abort()
+    t.join(timeout=10)
+    assert seen == ["released"]
