@@ -2,7 +2,12 @@
 // handle that every Processor kind shares: device selection, the handle's stream,
 // pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
 // bracket used for live kernel timing.
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -121,11 +126,92 @@ int validate_config(const pipe_hip_config *c)
 
 using namespace pipehip;
 
+// ---- large host calls: H2D(k + 1) | kernel(k) | D2H(k - 1) -------------------------------------
+// A call that brings many Lines (cfg.lines = L, one pipe buffer each: tens of MB) used to run
+// memcpy -> H2D -> kernels -> D2H -> memcpy strictly one after the other, the kernels 1 % of it.
+// Lines share no state (run.go:112-132), so the call is cut into chunks of whole Lines, each a
+// window of the handle (set_window): the caller's thread copies chunk k + 1 into pinned staging
+// while the DMA engine carries chunk k to the device on its own stream, the kernels of chunk k - 1
+// run on the handle's stream and the results of chunk k - 2 come back on a third; a worker thread
+// waits for every chunk's download and copies it out to the caller's buffers.  The same structure
+// as the capacity-1 channels between a pipe's stages (fitting.go:56-60), inside one call.
+struct pipe_hip_processor::Overlap {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev;  // [3 * chunk]: uploaded, computed, downloaded
+
+    // copy-out worker
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    std::deque<std::function<void()>> q;
+    int pending = 0;
+    bool stop = false;
+    int device = 0;
+
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return stop || !q.empty(); });
+            if (q.empty())
+                return;  // stop
+            std::function<void()> fn = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            fn();
+            lk.lock();
+            if (--pending == 0)
+                idle.notify_all();
+        }
+    }
+    void post(std::function<void()> fn)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!th.joinable())
+            th = std::thread([this] { loop(); });
+        q.push_back(std::move(fn));
+        ++pending;
+        cv.notify_one();
+    }
+    void wait_idle()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        idle.wait(lk, [this] { return pending == 0; });
+    }
+    int events(size_t n)
+    {
+        while (ev.size() < n) {
+            hipEvent_t e = nullptr;
+            PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+        }
+        return PIPE_HIP_OK;
+    }
+    ~Overlap()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable())
+            th.join();
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+        if (s_in)
+            (void)hipStreamDestroy(s_in);
+        if (s_out)
+            (void)hipStreamDestroy(s_out);
+    }
+};
+
 // ---- shared handle plumbing ---------------------------------------------------
 pipe_hip_processor::~pipe_hip_processor()
 {
     if (cfg.buffer_size > 0)
         (void)hipSetDevice(cfg.device);
+    delete overlap;
     if (stream) {
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
@@ -281,6 +367,105 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
         *out_frames = n;
     // (the buffer's event has been waited for: a device-side failure of its launches is known now)
     return p->poll_error();
+}
+
+struct WindowGuard {  // whatever happens, the handle goes back to "all Lines"
+    pipe_hip_processor *p;
+    ~WindowGuard() { p->set_window(0, 0); }
+};
+
+// Calls at least this large (input bytes) with two or more Lines are cut into chunks of Lines.
+size_t overlap_min_bytes()
+{
+    const char *e = std::getenv("PIPE_HIP_OVERLAP_MIN_BYTES");  // (read per call: tests switch it)
+    return e ? (size_t)std::atoll(e) : (size_t)4 << 20;
+}
+
+// Lines [first, first + count) of a fixed-rate handle, every one `frames` frames: in_of(l) /
+// out_of(l) are the HOST rows of Line l; the chunk rows sit packed in the handle's staging buffers
+// from byte in_off0 / out_off0.  Synchronous: on return the outputs are in the caller's buffers.
+int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t frames,
+                       const std::function<const void *(int)> &in_of, const std::function<void *(int)> &out_of,
+                       size_t in_off0, size_t out_off0)
+{
+    const int L = p->cfg.lines;
+    const size_t es = dtype_size(p->cfg.dtype);
+    const size_t row_in = es * (size_t)frames * (size_t)p->cfg.channels;
+    const size_t row_out = es * (size_t)frames * (size_t)p->out_channels();
+    if (!p->overlap) {
+        p->overlap = new pipe_hip_processor::Overlap();
+        p->overlap->device = p->cfg.device;
+    }
+    pipe_hip_processor::Overlap &ov = *p->overlap;
+    if (!ov.s_in) {
+        PH_HIP(hipStreamCreateWithFlags(&ov.s_in, hipStreamNonBlocking));
+        PH_HIP(hipStreamCreateWithFlags(&ov.s_out, hipStreamNonBlocking));
+    }
+    // chunks of about 8 MiB of input, at least four of them, whole Lines
+    const size_t total_in = row_in * (size_t)count;
+    size_t nchunks = total_in / ((size_t)8 << 20);
+    nchunks = nchunks < 4 ? 4 : (nchunks > 32 ? 32 : nchunks);
+    if (nchunks > (size_t)count)
+        nchunks = (size_t)count;
+    const int per = (int)((count + nchunks - 1) / nchunks);
+    nchunks = (size_t)((count + per - 1) / per);
+    PH_TRY(ov.events(3 * nchunks));
+    pipe_hip_processor::Staging &g = p->stg[0];
+    char *h_in = static_cast<char *>(g.h_in.p) + in_off0, *d_in = static_cast<char *>(g.d_in.p) + in_off0;
+    char *h_out = static_cast<char *>(g.h_out.p) + out_off0, *d_out = static_cast<char *>(g.d_out.p) + out_off0;
+    WindowGuard guard{p};
+    int rc = PIPE_HIP_OK;
+    std::mutex err_mu;
+    int worker_rc = PIPE_HIP_OK;
+    for (size_t c = 0; c < nchunks && rc == PIPE_HIP_OK; ++c) {
+        const int l0 = (int)c * per, n = (int)c * per + per <= count ? per : count - (int)c * per;
+        const size_t io = row_in * (size_t)l0, oo = row_out * (size_t)l0;
+        hipEvent_t up = ov.ev[3 * c], done = ov.ev[3 * c + 1], down = ov.ev[3 * c + 2];
+        for (int i = 0; i < n; ++i) {
+            const void *src = in_of(first + l0 + i);
+            if (src)
+                std::memcpy(h_in + io + row_in * (size_t)i, src, row_in);
+            else  // a Line that has ended rides along as silence, its state is dead
+                std::memset(h_in + io + row_in * (size_t)i, 0, row_in);
+        }
+        auto step = [&]() -> int {
+            PH_HIP(hipMemcpyAsync(d_in + io, h_in + io, row_in * (size_t)n, hipMemcpyHostToDevice, ov.s_in));
+            PH_HIP(hipEventRecord(up, ov.s_in));
+            PH_HIP(hipStreamWaitEvent(p->stream, up, 0));
+            p->set_window(first + l0, (first + l0 == 0 && n == L) ? 0 : n);
+            int64_t produced = frames;
+            PH_TRY(p->run_var(d_in + io, p->cfg.dtype, frames, d_out + oo, p->cfg.dtype, frames, &produced, p->stream));
+            PH_HIP(hipEventRecord(done, p->stream));
+            PH_HIP(hipStreamWaitEvent(ov.s_out, done, 0));
+            PH_HIP(hipMemcpyAsync(h_out + oo, d_out + oo, row_out * (size_t)n, hipMemcpyDeviceToHost, ov.s_out));
+            PH_HIP(hipEventRecord(down, ov.s_out));
+            return PIPE_HIP_OK;
+        };
+        rc = step();
+        if (rc != PIPE_HIP_OK)
+            break;
+        ov.post([&, down, l0, n, oo] {
+            if (hipEventSynchronize(down) != hipSuccess) {
+                (void)hipGetLastError();
+                std::lock_guard<std::mutex> lk(err_mu);
+                worker_rc = PIPE_HIP_EHIP;
+                return;
+            }
+            for (int i = 0; i < n; ++i) {
+                void *dst = out_of(first + l0 + i);
+                if (dst)
+                    std::memcpy(dst, h_out + oo + row_out * (size_t)i, row_out);
+            }
+        });
+    }
+    ov.wait_idle();  // (also on an error: the worker's closures point into this frame)
+    if (rc != PIPE_HIP_OK) {
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipStreamSynchronize(ov.s_out);
+        return rc;
+    }
+    PH_HIP(hipStreamSynchronize(p->stream));
+    return worker_rc;
 }
 
 }  // namespace
@@ -449,6 +634,25 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         return PIPE_HIP_EINVAL;
     if (p->in_flight)  // collect would hand back an older buffer
         return PIPE_HIP_ESTATE;
+    // many Lines in one call: chunks of Lines, transfers and kernels overlapped
+    if (p->fixed_rate() && p->single_input() && p->cfg.lines >= 2 && in && out && in_frames > 0 &&
+        in_frames <= p->cfg.buffer_size && in_frames <= out_cap_frames) {
+        const size_t es = dtype_size(p->cfg.dtype);
+        const size_t row_in = es * (size_t)in_frames * (size_t)p->cfg.channels;
+        const size_t row_out = es * (size_t)in_frames * (size_t)p->out_channels();
+        if (row_in * (size_t)p->cfg.lines >= overlap_min_bytes()) {
+            PH_TRY(p->select_device());
+            PH_TRY(p->ensure_staging());
+            const char *ib = static_cast<const char *>(in);
+            char *ob = static_cast<char *>(out);
+            PH_TRY(process_overlapped(
+                p, 0, p->cfg.lines, in_frames, [=](int l) -> const void * { return ib + row_in * (size_t)l; },
+                [=](int l) -> void * { return ob + row_out * (size_t)l; }, 0, 0));
+            if (out_frames)
+                *out_frames = in_frames;
+            return p->poll_error();
+        }
+    }
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
     return collect_impl(p, out, out_cap_frames, out_frames);
 }
@@ -516,11 +720,6 @@ int plan_line_runs(const pipe_hip_processor *p, const void *const *ins, const in
     return PIPE_HIP_OK;
 }
 
-struct WindowGuard {  // whatever happens, the handle goes back to "all Lines"
-    pipe_hip_processor *p;
-    ~WindowGuard() { p->set_window(0, 0); }
-};
-
 }  // namespace
 
 int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
@@ -541,6 +740,16 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
     if (runs.empty())
         return PIPE_HIP_OK;
     const size_t es = dtype_size(p->cfg.dtype);
+    // the usual pass -- one run, many Lines, tens of MB: chunks of Lines, transfers and kernels overlapped
+    if (runs.size() == 1 && runs[0].count >= 2 &&
+        es * (size_t)runs[0].frames * (size_t)p->cfg.channels * (size_t)runs[0].count >= overlap_min_bytes()) {
+        const LineRun &r = runs[0];
+        PH_TRY(process_overlapped(
+            p, r.first, r.count, r.frames,
+            [=](int l) -> const void * { return ins[l] && in_frames[l] > 0 ? ins[l] : nullptr; },
+            [=](int l) -> void * { return ins[l] && in_frames[l] > 0 ? outs[l] : nullptr; }, r.in_off, r.out_off));
+        return p->poll_error();
+    }
     WindowGuard guard{p};
     // gather: Line l of a run occupies [l - first][frames][channels] of the run's staging rows
     for (const LineRun &r : runs) {

@@ -194,6 +194,10 @@ struct pipe_hip_processor {
     int in_flight = 0;     // buffers submitted and not collected (0..2); the oldest sits in
                            // slot (submit_slot - in_flight) & 1
     pipehip::PinnedBuf line_tab;  // pointer / length tables of process_lines_pinned
+    // large host calls: copy streams, per-chunk events and the copy-out worker (abi.hip), made on
+    // first use and released by the destructor
+    struct Overlap;
+    Overlap *overlap = nullptr;
     bool owned_by_chain = false;
     // set by a chain for a stage whose float64 output feeds a chain that ends in float32:
     // the stage may then use a form that is exact to O(1e-16) instead of bit-exact
