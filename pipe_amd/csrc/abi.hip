@@ -2,6 +2,7 @@
 // handle that every Processor kind shares: device selection, the handle's stream,
 // pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
 // bracket used for live kernel timing.
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -139,45 +140,156 @@ struct pipe_hip_processor::Overlap {
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> ev;  // [3 * chunk]: uploaded, computed, downloaded
 
-    // copy-out worker
-    std::thread th;
+    // One call at a time (the entry points are synchronous): what its tasks need.
+    struct Call {
+        pipe_hip_processor *p;
+        int first, count, per;
+        int32_t frames;
+        size_t row_in, row_out, nchunks;
+        char *h_in, *d_in, *h_out, *d_out;
+        const std::function<const void *(int)> *in_of;
+        const std::function<void *(int)> *out_of;
+        bool bar = false;    // the CPU stores the rows straight into device memory (large BAR): no upload DMA
+        std::mutex enq_mu;   // the handle is not thread-safe: one chunk is queued at a time
+        int rc = PIPE_HIP_OK;
+        size_t finished = 0;  // chunks copied out (or given up on)
+        bool trace = false;
+        std::chrono::steady_clock::time_point t0;
+        std::vector<double> tr;
+        double us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+    };
+
+    // Copy threads: the caller plus `extra` workers.  A chunk is two tasks -- IN: copy its rows into
+    // pinned staging, queue upload / kernels / download; OUT: wait for the download, copy the rows to
+    // the caller's buffers.  A thread prefers an OUT whose download has landed, then an IN, and only
+    // blocks on a download when nothing else is left: the host copies (about 18 GB/s per thread on
+    // this box) are the slowest part of the call, several threads share them.
+    std::vector<std::thread> ths;
     std::mutex mu;
     std::condition_variable cv, idle;
-    std::deque<std::function<void()>> q;
-    int pending = 0;
+    std::deque<size_t> q_in, q_out;
+    Call *call = nullptr;
     bool stop = false;
     int device = 0;
 
+    static int copy_threads()
+    {
+        const char *e = std::getenv("PIPE_HIP_COPY_THREADS");
+        int n = e ? std::atoi(e) : 4;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw)
+            n = hw;
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }
+
+    int task_in(Call &c, size_t k)
+    {
+        const int l0 = (int)k * c.per, n = l0 + c.per <= c.count ? c.per : c.count - l0;
+        const size_t io = c.row_in * (size_t)l0, oo = c.row_out * (size_t)l0;
+        char *dst_rows = (c.bar ? c.d_in : c.h_in) + io;
+        for (int i = 0; i < n; ++i) {
+            const void *src = (*c.in_of)(c.first + l0 + i);
+            if (src)
+                std::memcpy(dst_rows + c.row_in * (size_t)i, src, c.row_in);
+            else  // a Line that has ended rides along as silence, its state is dead
+                std::memset(dst_rows + c.row_in * (size_t)i, 0, c.row_in);
+        }
+        if (c.bar)
+            __builtin_ia32_sfence();  // the write-combined stores have left the core before the launch's doorbell
+        if (c.trace)
+            c.tr[k * 5] = c.us();
+        pipe_hip_processor *p = c.p;
+        std::lock_guard<std::mutex> lk(c.enq_mu);
+        hipEvent_t up = ev[3 * k], done = ev[3 * k + 1], down = ev[3 * k + 2];
+        if (!c.bar) {
+            PH_HIP(hipMemcpyAsync(c.d_in + io, c.h_in + io, c.row_in * (size_t)n, hipMemcpyHostToDevice, s_in));
+            PH_HIP(hipEventRecord(up, s_in));
+            PH_HIP(hipStreamWaitEvent(p->stream, up, 0));
+        }
+        p->set_window(c.first + l0, (c.first + l0 == 0 && n == p->cfg.lines) ? 0 : n);
+        int64_t produced = c.frames;
+        PH_TRY(p->run_var(c.d_in + io, p->cfg.dtype, c.frames, c.d_out + oo, p->cfg.dtype, c.frames, &produced, p->stream));
+        PH_HIP(hipEventRecord(done, p->stream));
+        PH_HIP(hipStreamWaitEvent(s_out, done, 0));
+        PH_HIP(hipMemcpyAsync(c.h_out + oo, c.d_out + oo, c.row_out * (size_t)n, hipMemcpyDeviceToHost, s_out));
+        PH_HIP(hipEventRecord(down, s_out));
+        if (c.trace)
+            c.tr[k * 5 + 1] = c.us();
+        return PIPE_HIP_OK;
+    }
+    int task_out(Call &c, size_t k)
+    {
+        const int l0 = (int)k * c.per, n = l0 + c.per <= c.count ? c.per : c.count - l0;
+        const size_t oo = c.row_out * (size_t)l0;
+        if (c.trace)
+            c.tr[k * 5 + 2] = c.us();
+        PH_HIP(hipEventSynchronize(ev[3 * k + 2]));
+        if (c.trace)
+            c.tr[k * 5 + 3] = c.us();
+        for (int i = 0; i < n; ++i) {
+            void *dst = (*c.out_of)(c.first + l0 + i);
+            if (dst)
+                std::memcpy(dst, c.h_out + oo + c.row_out * (size_t)i, c.row_out);
+        }
+        if (c.trace)
+            c.tr[k * 5 + 4] = c.us();
+        return PIPE_HIP_OK;
+    }
+    // run tasks until both queues are empty (called with `lk` held; returns with it held)
+    void drain(std::unique_lock<std::mutex> &lk)
+    {
+        while (call && (!q_in.empty() || !q_out.empty())) {
+            Call &c = *call;
+            bool out = false;
+            size_t k = 0;
+            if (!q_out.empty() && (q_in.empty() || hipEventQuery(ev[3 * q_out.front() + 2]) == hipSuccess)) {
+                out = true;
+                k = q_out.front();
+                q_out.pop_front();
+            } else {
+                (void)hipGetLastError();  // (hipErrorNotReady from the query)
+                k = q_in.front();
+                q_in.pop_front();
+            }
+            lk.unlock();
+            const int rc = out ? task_out(c, k) : task_in(c, k);
+            lk.lock();
+            if (rc != PIPE_HIP_OK && c.rc == PIPE_HIP_OK)
+                c.rc = rc;
+            if (!out && rc == PIPE_HIP_OK) {
+                q_out.push_back(k);
+                cv.notify_one();
+            } else if (++c.finished == c.nchunks) {
+                idle.notify_all();
+            }
+        }
+    }
     void loop()
     {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv.wait(lk, [this] { return stop || !q.empty(); });
-            if (q.empty())
-                return;  // stop
-            std::function<void()> fn = std::move(q.front());
-            q.pop_front();
-            lk.unlock();
-            fn();
-            lk.lock();
-            if (--pending == 0)
-                idle.notify_all();
+            cv.wait(lk, [this] { return stop || (call && (!q_in.empty() || !q_out.empty())); });
+            if (stop)
+                return;
+            drain(lk);
         }
     }
-    void post(std::function<void()> fn)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!th.joinable())
-            th = std::thread([this] { loop(); });
-        q.push_back(std::move(fn));
-        ++pending;
-        cv.notify_one();
-    }
-    void wait_idle()
+    // the caller's side: all chunks of one call
+    int run(Call &c)
     {
         std::unique_lock<std::mutex> lk(mu);
-        idle.wait(lk, [this] { return pending == 0; });
+        const int want = copy_threads() - 1;
+        while ((int)ths.size() < want)
+            ths.emplace_back([this] { loop(); });
+        call = &c;
+        for (size_t k = 0; k < c.nchunks; ++k)
+            q_in.push_back(k);
+        cv.notify_all();
+        drain(lk);
+        idle.wait(lk, [&] { return c.finished == c.nchunks; });
+        call = nullptr;
+        return c.rc;
     }
     int events(size_t n)
     {
@@ -195,8 +307,8 @@ struct pipe_hip_processor::Overlap {
             stop = true;
             cv.notify_all();
         }
-        if (th.joinable())
-            th.join();
+        for (std::thread &t : ths)
+            t.join();
         for (hipEvent_t e : ev)
             (void)hipEventDestroy(e);
         if (s_in)
@@ -388,7 +500,6 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
                        const std::function<const void *(int)> &in_of, const std::function<void *(int)> &out_of,
                        size_t in_off0, size_t out_off0)
 {
-    const int L = p->cfg.lines;
     const size_t es = dtype_size(p->cfg.dtype);
     const size_t row_in = es * (size_t)frames * (size_t)p->cfg.channels;
     const size_t row_out = es * (size_t)frames * (size_t)p->out_channels();
@@ -401,9 +512,9 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
         PH_HIP(hipStreamCreateWithFlags(&ov.s_in, hipStreamNonBlocking));
         PH_HIP(hipStreamCreateWithFlags(&ov.s_out, hipStreamNonBlocking));
     }
-    // chunks of about 8 MiB of input, at least four of them, whole Lines
+    // chunks of about 4 MiB of input, at least four of them, whole Lines
     const size_t total_in = row_in * (size_t)count;
-    size_t nchunks = total_in / ((size_t)8 << 20);
+    size_t nchunks = total_in / ((size_t)4 << 20);
     nchunks = nchunks < 4 ? 4 : (nchunks > 32 ? 32 : nchunks);
     if (nchunks > (size_t)count)
         nchunks = (size_t)count;
@@ -411,61 +522,56 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
     nchunks = (size_t)((count + per - 1) / per);
     PH_TRY(ov.events(3 * nchunks));
     pipe_hip_processor::Staging &g = p->stg[0];
-    char *h_in = static_cast<char *>(g.h_in.p) + in_off0, *d_in = static_cast<char *>(g.d_in.p) + in_off0;
-    char *h_out = static_cast<char *>(g.h_out.p) + out_off0, *d_out = static_cast<char *>(g.d_out.p) + out_off0;
-    WindowGuard guard{p};
-    int rc = PIPE_HIP_OK;
-    std::mutex err_mu;
-    int worker_rc = PIPE_HIP_OK;
-    for (size_t c = 0; c < nchunks && rc == PIPE_HIP_OK; ++c) {
-        const int l0 = (int)c * per, n = (int)c * per + per <= count ? per : count - (int)c * per;
-        const size_t io = row_in * (size_t)l0, oo = row_out * (size_t)l0;
-        hipEvent_t up = ov.ev[3 * c], done = ov.ev[3 * c + 1], down = ov.ev[3 * c + 2];
-        for (int i = 0; i < n; ++i) {
-            const void *src = in_of(first + l0 + i);
-            if (src)
-                std::memcpy(h_in + io + row_in * (size_t)i, src, row_in);
-            else  // a Line that has ended rides along as silence, its state is dead
-                std::memset(h_in + io + row_in * (size_t)i, 0, row_in);
-        }
-        auto step = [&]() -> int {
-            PH_HIP(hipMemcpyAsync(d_in + io, h_in + io, row_in * (size_t)n, hipMemcpyHostToDevice, ov.s_in));
-            PH_HIP(hipEventRecord(up, ov.s_in));
-            PH_HIP(hipStreamWaitEvent(p->stream, up, 0));
-            p->set_window(first + l0, (first + l0 == 0 && n == L) ? 0 : n);
-            int64_t produced = frames;
-            PH_TRY(p->run_var(d_in + io, p->cfg.dtype, frames, d_out + oo, p->cfg.dtype, frames, &produced, p->stream));
-            PH_HIP(hipEventRecord(done, p->stream));
-            PH_HIP(hipStreamWaitEvent(ov.s_out, done, 0));
-            PH_HIP(hipMemcpyAsync(h_out + oo, d_out + oo, row_out * (size_t)n, hipMemcpyDeviceToHost, ov.s_out));
-            PH_HIP(hipEventRecord(down, ov.s_out));
-            return PIPE_HIP_OK;
-        };
-        rc = step();
-        if (rc != PIPE_HIP_OK)
-            break;
-        ov.post([&, down, l0, n, oo] {
-            if (hipEventSynchronize(down) != hipSuccess) {
+    pipe_hip_processor::Overlap::Call c{};
+    c.p = p;
+    c.first = first;
+    c.count = count;
+    c.per = per;
+    c.frames = frames;
+    c.row_in = row_in;
+    c.row_out = row_out;
+    c.nchunks = nchunks;
+    c.h_in = static_cast<char *>(g.h_in.p) + in_off0;
+    c.d_in = static_cast<char *>(g.d_in.p) + in_off0;
+    c.h_out = static_cast<char *>(g.h_out.p) + out_off0;
+    c.d_out = static_cast<char *>(g.d_out.p) + out_off0;
+    c.in_of = &in_of;
+    c.out_of = &out_of;
+    // Large BAR: device memory is mapped into the host's address space, so the copy INTO staging can
+    // be the upload itself (one pass over the caller's rows, write-combined stores over PCIe) instead
+    // of a copy into pinned memory plus a DMA.  PIPE_HIP_BAR_UPLOAD=0 keeps the DMA path.
+    {
+        static const int large_bar = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) {
                 (void)hipGetLastError();
-                std::lock_guard<std::mutex> lk(err_mu);
-                worker_rc = PIPE_HIP_EHIP;
-                return;
+                return 0;
             }
-            for (int i = 0; i < n; ++i) {
-                void *dst = out_of(first + l0 + i);
-                if (dst)
-                    std::memcpy(dst, h_out + oo + row_out * (size_t)i, row_out);
-            }
-        });
+            return v;
+        }();
+        const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD");
+        c.bar = large_bar != 0 && !(e && e[0] == '0');
     }
-    ov.wait_idle();  // (also on an error: the worker's closures point into this frame)
-    if (rc != PIPE_HIP_OK) {
-        (void)hipStreamSynchronize(p->stream);
-        (void)hipStreamSynchronize(ov.s_out);
+    c.trace = std::getenv("PIPE_HIP_OVERLAP_TRACE") != nullptr;  // debug: where a call's time goes
+    c.t0 = std::chrono::steady_clock::now();
+    c.tr.assign(c.trace ? nchunks * 5 : 0, 0.0);
+    WindowGuard guard{p};
+    const int rc = ov.run(c);
+    // (on an error too: nothing of this call may still be running when its frame goes away)
+    const hipError_t e1 = hipStreamSynchronize(p->stream), e2 = hipStreamSynchronize(ov.s_out);
+    if (rc != PIPE_HIP_OK)
         return rc;
+    PH_HIP(e1);
+    PH_HIP(e2);
+    if (c.trace) {
+        std::fprintf(stderr, "[overlap] %zu chunks of %d Lines, %d copy threads, %.0f us; per chunk (us since the call began): "
+                             "copied in, queued | picked up for copy-out, downloaded, copied out\n",
+                     nchunks, per, pipe_hip_processor::Overlap::copy_threads(), c.us());
+        for (size_t k = 0; k < nchunks; ++k)
+            std::fprintf(stderr, "[overlap]   %2zu: %7.0f %7.0f | %7.0f %7.0f %7.0f\n", k, c.tr[k * 5], c.tr[k * 5 + 1],
+                         c.tr[k * 5 + 2], c.tr[k * 5 + 3], c.tr[k * 5 + 4]);
     }
-    PH_HIP(hipStreamSynchronize(p->stream));
-    return worker_rc;
+    return PIPE_HIP_OK;
 }
 
 }  // namespace
