@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include <hip/hip_ext.h>
 
@@ -359,6 +360,327 @@ __global__ void __launch_bounds__(kThreads) resample_tiled_kernel(const TiledArg
     }
 }
 
+// ---- two adjacent outputs per lane: 2-channel streams, taps in registers ----------------------------
+// The tiled kernel above reads the window once per OUTPUT: 2 T ds_read_b64 per output frame, and the
+// LDS is what bounds it.  Two ADJACENT outputs m, m + 1 read nearly the same frames: output m reads
+// x[n - j], output m + 1 reads x[n + d - j] with d = floor((t + down) / up) - floor(t / up), which is
+// DMIN = down / up or DMIN + 1 -- fixed per lane when a lane's outputs are a multiple of `up` apart
+// (the same condition that lets it keep its taps in registers).  A lane therefore takes outputs
+// (2 l, 2 l + 1) of every step of 2 ql outputs (2 ql a multiple of up), reads the W = T + DMIN + 1
+// frames X[i] = x[n + DMIN + 1 - i] once per channel and feeds both sums:
+//     A (output m)    : sum_j hA[j]  X[DMIN + 1 + j]
+//     B (output m + 1): sum_j hB[j]  X[1 - e + j],      e = d - DMIN in {0, 1}
+// B's taps are stored shifted by the lane's e (hB'[i] = hB[i - 1 + e]), so every register index is a
+// compile-time constant; the two end positions that one value of e does not use are skipped with a
+// select, not multiplied by a zero tap (0 x Inf would be NaN where the oracle never touches that
+// sample).  Same operations in the same order per output as the oracle: bit-exact.  LDS reads per
+// output frame: 48 -> 25 (160/147) or 26 (147/160).
+// Staging moves 16 bytes per lane (two float32 frames of both channels, or one float64 frame) and is
+// double-buffered: the next tile's window is requested before this tile's outputs are computed and
+// written to the other pair of planes afterwards, one barrier per tile.
+struct PairArgs {
+    ResampleArgs r;
+    int win;        // staged frames per tile (even)
+    int plane;      // plane stride (doubles, 16-byte aligned planes)
+    int tiles_per_line;
+    int tile_out;   // outputs per tile = 2 * ql * steps
+    int ql;         // computing lanes
+    int steps;
+    int adv;        // input frames a step advances: 2 * ql * down / up
+    int vec_ok;     // every Line's input starts 16-byte aligned
+    int lead;       // virtual outputs ahead of the call's first one: tiles start where the phase is 0
+    int64_t nb;     // input frame (relative to this call) the first virtual output reads
+    const double *ptaps;  // [2 T + 1][ql]: the lanes' taps, hA rows then the shifted hB rows
+    unsigned long long *prof;  // PH_RS_PROF builds: [wave][5] s_memtime ticks per phase
+};
+#ifdef PH_RS_PROF
+#define PH_RS_STAMP(i)                                                  \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        rsprof[i] += now_ - rslast;                                     \
+        rslast = now_;                                                  \
+    } while (0)
+#else
+#define PH_RS_STAMP(i) \
+    do {               \
+    } while (0)
+#endif
+constexpr int kPairPad = 4;   // frames staged below the oldest one a tile's first output reads (grouped reads overshoot)
+constexpr int kPairVecs = 3;  // pieces of the window a thread stages per tile, at most (registers: three waves per SIMD)
+
+template <int CNT>
+__device__ __forceinline__ void lds_wait_cnt()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_pin(double (&v)[N])  // uses of v stay behind the wait above
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        asm volatile("" : "+v"(v[i]));
+}
+// v[i] = X[G0 + i], X[pos] at byte offset 8 * (NPOS - 1 - pos) above `lo`
+template <int G0, int NPOS, int N, int... I>
+__device__ __forceinline__ void lds_read_pos(double (&v)[N], unsigned lo, std::integer_sequence<int, I...>)
+{
+    ((v[I] = lds_read_f64<8 * (NPOS - 1 - (G0 + I))>(lo)), ...);
+}
+template <typename F, int... Gs>
+__device__ __forceinline__ void for_each_const(std::integer_sequence<int, Gs...>, F &&f)
+{
+    (f(std::integral_constant<int, Gs>{}), ...);
+}
+
+template <typename T>
+struct PairRaw;  // one 16-byte (float32: two frames) / 32-byte (float64: two frames) piece of the window
+template <>
+struct PairRaw<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
+    {
+        c0[0] = (double)v.x;
+        c1[0] = (double)v.y;
+        c0[1] = (double)v.z;
+        c1[1] = (double)v.w;
+    }
+};
+template <>
+struct PairRaw<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double *p)
+    {
+        a = *reinterpret_cast<const double2 *>(p);
+        b = *reinterpret_cast<const double2 *>(p + 2);
+    }
+    __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
+    {
+        c0[0] = a.x;
+        c1[0] = a.y;
+        c0[1] = b.x;
+        c1[1] = b.y;
+    }
+};
+
+// Ablation builds (scripts/build_ablate_lib.sh; never the shipped library): 1 = no tap loops
+// (staging and stores only), 2 = tap loops without their LDS reads, 3 = no staging, 4 = no stores
+#ifndef PH_RS_ABLATE
+#define PH_RS_ABLATE 0
+#endif
+
+template <typename TIn, typename TOut, int TT, int DMIN>
+__global__ void __launch_bounds__(kThreads) resample_pair_kernel(const PairArgs t)  // (launched with 64..256 threads)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *bufs = reinterpret_cast<double *>(smem_raw);  // [2 tiles][2 channels][plane]
+    const ResampleArgs &a = t.r;
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    constexpr int H = TT - 1;
+    constexpr int W = TT + DMIN + 1;  // frames a pair reads
+    constexpr int G = 4, NG = (W + G - 1) / G, NPOS = NG * G;
+
+#ifdef PH_RS_PROF
+    unsigned long long rsprof[5] = {}, rslast = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the lane's two outputs (fixed for the whole launch).  Tiles start at outputs whose phase is 0
+    // (multiples of `up` counted from Start), so a lane's phases, offset and taps do not depend on the
+    // call: they come from a table made once, one coalesced load per tap.
+    const bool computing = tid < t.ql;
+    const unsigned ltid = computing ? (unsigned)tid : 0u;
+    const unsigned ttA = 2u * ltid * (unsigned)a.down, nA = ttA / (unsigned)a.up;
+    const unsigned nB = (ttA + (unsigned)a.down) / (unsigned)a.up;
+    const bool e1 = (int)(nB - nA) - DMIN != 0;  // e = 1: output B reads X[0 .. T-1]; e = 0: X[1 .. T]
+    double hA[TT], hB[TT + 1];
+    auto load_taps = [&]() {
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+            hA[j] = t.ptaps[j * t.ql + ltid];
+#pragma unroll
+        for (int i = 0; i <= TT; ++i)
+            hB[i] = t.ptaps[(TT + i) * t.ql + ltid];
+    };
+
+    const int ntiles = t.tiles_per_line * a.lines;
+    const int npairs = t.win / 2;
+
+    // window geometry of a tile (no division beyond the Line split: tiles are whole periods)
+    auto geometry = [&](int tile_id, int &line, int64_t &i0, int64_t &base_e, int &odd) {
+        line = a.lines == 1 ? 0 : tile_id / t.tiles_per_line;
+        const int tile = tile_id - line * t.tiles_per_line;
+        i0 = (int64_t)tile * t.tile_out - t.lead;        // (negative: the virtual outputs ahead of the call)
+        const int64_t nfirst = t.nb + (int64_t)tile * (t.steps * t.adv);  // frame the tile's first output reads
+        const int64_t base = nfirst - H - kPairPad;
+        base_e = base & ~(int64_t)1;  // even: 16-byte pieces of the input, 16-byte plane cells
+        odd = (int)(base - base_e);
+    };
+    // frame g (relative to this call's input) of channel c, the slow way: history below 0, silence past the end
+    auto frame_value = [&](const TIn *__restrict__ in, const double *__restrict__ hist, int64_t g, int c) -> double {
+        if (g >= 0)
+            return g < a.in_frames ? (double)in[g * 2 + c] : 0.0;
+        return g >= -(int64_t)H ? hist[(g + H) * 2 + c] : 0.0;
+    };
+
+    PairRaw<TIn> pre[kPairVecs];
+    unsigned fast = 0;  // bit k: vector k of the prefetched tile is a plain 16-byte piece of the input
+    auto request = [&](int tile_id) {
+        int line, odd;
+        int64_t i0, base_e;
+        geometry(tile_id, line, i0, base_e, odd);
+        const TIn *__restrict__ in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * 2;
+        fast = 0;
+#pragma unroll
+        for (int k = 0; k < kPairVecs; ++k) {
+            const int pr = tid + k * nthr;
+            const int64_t g = base_e + 2 * pr;
+            if (pr < npairs && t.vec_ok && g >= 0 && g + 1 < a.in_frames) {
+                pre[k].load(in + g * 2);
+                fast |= 1u << k;
+            }
+        }
+    };
+    auto deposit = [&](int tile_id, double *dst) {
+        int line, odd;
+        int64_t i0, base_e;
+        geometry(tile_id, line, i0, base_e, odd);
+        const TIn *__restrict__ in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * 2;
+        const double *__restrict__ hist = a.hist + (int64_t)line * H * 2;
+#pragma unroll
+        for (int k = 0; k < kPairVecs; ++k) {
+            const int pr = tid + k * nthr;
+            if (pr >= npairs)
+                continue;
+            double c0[2], c1[2];
+            if (fast & (1u << k)) {
+                pre[k].widen(c0, c1);
+            } else {
+                const int64_t g = base_e + 2 * pr;
+                c0[0] = frame_value(in, hist, g, 0);
+                c1[0] = frame_value(in, hist, g, 1);
+                c0[1] = frame_value(in, hist, g + 1, 0);
+                c1[1] = frame_value(in, hist, g + 1, 1);
+            }
+            *reinterpret_cast<double2 *>(dst + 2 * pr) = double2{c0[0], c0[1]};
+            *reinterpret_cast<double2 *>(dst + t.plane + 2 * pr) = double2{c1[0], c1[1]};
+        }
+    };
+
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles && PH_RS_ABLATE != 3)
+        request((int)blockIdx.x);
+    load_taps();  // (behind the first window's requests: both fly together)
+    if ((int)blockIdx.x < ntiles && PH_RS_ABLATE != 3)
+        deposit((int)blockIdx.x, bufs);
+    __syncthreads();
+    PH_RS_STAMP(0);
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int next = tile_id + (int)gridDim.x;
+        if (next < ntiles && PH_RS_ABLATE != 3)
+            request(next);  // flies under this tile's tap loops
+        PH_RS_STAMP(1);
+
+        int line, odd;
+        int64_t i0, base_e;
+        geometry(tile_id, line, i0, base_e, odd);
+        // outputs [lo, nout) of the tile are the call's (lo > 0 only in a Line's first tile)
+        const int nout = (int)min((int64_t)t.tile_out, a.out_frames - i0);
+        const int lo = i0 < 0 ? (int)-i0 : 0;
+        TOut *__restrict__ out = reinterpret_cast<TOut *>(a.out) + ((int64_t)line * a.out_cap + i0) * 2;
+        const double *P0 = bufs + (size_t)cur * 2 * t.plane;
+        typedef __attribute__((address_space(3))) const double *lds_ptr;
+        if (computing) {
+            for (int s = 0; s < t.steps; ++s) {
+                const int mlA = s * 2 * t.ql + 2 * tid;
+                if (mlA >= nout)
+                    break;
+                if (mlA + 1 < lo)
+                    continue;
+                // plane cell of X[0] = x[nfirst + nrelA + DMIN + 1]; X[pos] sits pos cells below
+                const int idx0 = H + kPairPad + odd + (int)nA + s * t.adv + DMIN + 1;
+                const unsigned lo0 = (unsigned)(uintptr_t)(lds_ptr)(P0 + idx0 - (NPOS - 1));
+                const unsigned lo1 = lo0 + 8u * (unsigned)t.plane;
+                double accA0 = 0.0, accA1 = 0.0, accB0 = 0.0, accB1 = 0.0;
+                double v0[2][G], v1[2][G];
+#if PH_RS_ABLATE == 2
+                for (int i = 0; i < G; ++i)
+                    v0[0][i] = v0[1][i] = v1[0][i] = v1[1][i] = (double)(lo0 + lo1 + i);
+#else
+                lds_read_pos<0, NPOS>(v0[0], lo0, std::make_integer_sequence<int, G>{});
+                lds_read_pos<0, NPOS>(v1[0], lo1, std::make_integer_sequence<int, G>{});
+#endif
+                for_each_const(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (PH_RS_ABLATE == 1 || PH_RS_ABLATE == 2) {
+                        if constexpr (PH_RS_ABLATE == 1)
+                            return;
+                    } else if constexpr (g + 1 < NG) {
+                        lds_read_pos<(g + 1) * G, NPOS>(v0[(g + 1) & 1], lo0, std::make_integer_sequence<int, G>{});
+                        lds_read_pos<(g + 1) * G, NPOS>(v1[(g + 1) & 1], lo1, std::make_integer_sequence<int, G>{});
+                        lds_wait_cnt<2 * G>();
+                    } else {
+                        lds_wait_cnt<0>();
+                    }
+                    lds_pin(v0[g & 1]);
+                    lds_pin(v1[g & 1]);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int pos = g * G + i;
+                        const double x0 = v0[g & 1][i], x1 = v1[g & 1][i];
+                        if (pos <= TT) {  // output B
+                            const double b0 = __builtin_fma(hB[pos < TT + 1 ? pos : 0], x0, accB0);
+                            const double b1 = __builtin_fma(hB[pos < TT + 1 ? pos : 0], x1, accB1);
+                            if (pos == 0) {
+                                accB0 = e1 ? b0 : accB0;
+                                accB1 = e1 ? b1 : accB1;
+                            } else if (pos == TT) {
+                                accB0 = e1 ? accB0 : b0;
+                                accB1 = e1 ? accB1 : b1;
+                            } else {
+                                accB0 = b0;
+                                accB1 = b1;
+                            }
+                        }
+                        if (pos >= DMIN + 1 && pos <= DMIN + TT) {  // output A
+                            accA0 = __builtin_fma(hA[pos - DMIN - 1 < TT && pos >= DMIN + 1 ? pos - DMIN - 1 : 0], x0, accA0);
+                            accA1 = __builtin_fma(hA[pos - DMIN - 1 < TT && pos >= DMIN + 1 ? pos - DMIN - 1 : 0], x1, accA1);
+                        }
+                    }
+                    // this group's fma stay ahead of the reads of the group after next (the sums are
+                    // otherwise sunk below every read: all W x 2 values live at once): the accumulators
+                    // pass through the ordered asm stream, and the scheduler may not cross the barrier
+                    asm volatile("" : "+v"(accA0), "+v"(accA1), "+v"(accB0), "+v"(accB1));
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                TOut *__restrict__ o = out + (int64_t)mlA * 2;
+                if (PH_RS_ABLATE == 4 && accA0 + accA1 + accB0 + accB1 != 12345.678)
+                    continue;
+                if (mlA >= lo) {
+                    o[0] = (TOut)accA0;
+                    o[1] = (TOut)accA1;
+                }
+                if (mlA + 1 < nout) {
+                    o[2] = (TOut)accB0;
+                    o[3] = (TOut)accB1;
+                }
+            }
+        }
+        PH_RS_STAMP(2);
+        if (next < ntiles && PH_RS_ABLATE != 3)
+            deposit(next, bufs + (size_t)(cur ^ 1) * 2 * t.plane);
+        PH_RS_STAMP(3);
+        __syncthreads();
+        PH_RS_STAMP(4);
+        cur ^= 1;
+    }
+#ifdef PH_RS_PROF
+    if (t.prof && (threadIdx.x & 63) == 0) {
+        unsigned long long *dst = t.prof + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 5;
+        for (int i = 0; i < 5; ++i)
+            dst[i] = rsprof[i];
+    }
+#endif
+}
+
 template <typename TIn>
 __global__ void resample_hist_kernel(const TIn *__restrict__ in, const double *__restrict__ hist_old,
                                      double *__restrict__ hist_new, int64_t frames, int H, int C)
@@ -388,6 +710,7 @@ public:
         const size_t n = (size_t)up * (size_t)T;
         PH_TRY(proto_.alloc(sizeof(double) * n));
         PH_HIP(hipMemcpy(proto_.p, proto, sizeof(double) * n, hipMemcpyHostToDevice));
+        host_proto_.assign(proto, proto + n);
         hist_bytes_ = sizeof(double) * (size_t)cfg.lines * (size_t)(T - 1) * (size_t)cfg.channels;
         PH_TRY(hist_[0].alloc(hist_bytes_));
         PH_TRY(hist_[1].alloc(hist_bytes_));
@@ -487,6 +810,10 @@ public:
                     break;
             }
         }
+        // 2-channel streams with the taps in registers: two adjacent outputs per lane share their
+        // window reads (resample_pair_kernel)
+        if (total > 0 && n_out > 0 && launch_pair(a, in_dtype, out_dtype, reg_taps, s))
+            return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         const bool big_lds = lds > 64 * 1024;
         const bool tiled = lds <= (reg_taps ? (size_t)64 * 1024 : kBigLds) && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
         if (total > 0 && tiled) {
@@ -572,6 +899,13 @@ public:
             PH_HIP(hipGetLastError());
             PH_TRY(timer.end(s));
         }
+        return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
+    }
+
+private:
+    // the history for the next call, the stream's counters
+    int finish_call(const void *d_in, int in_dtype, int64_t in_frames, int64_t n_out, const ResampleArgs &a, hipStream_t s)
+    {
         const int H = T_ - 1;
         if (H > 0) {
             const int n = H * cfg.channels;
@@ -596,8 +930,169 @@ public:
         return PIPE_HIP_OK;
     }
 
-private:
+    // the lanes' taps of the pair kernel, [2 T + 1][ql]: rows 0 .. T-1 output A's taps, rows T .. 2T
+    // output B's shifted by the lane's e (resample_pair_kernel); made once per (ql, dmin)
+    bool ensure_pair_taps(int ql, int dmin)
+    {
+        if (pair_taps_.p && pair_ql_ == ql)
+            return true;
+        const size_t n = (size_t)(2 * T_ + 1) * (size_t)ql;
+        std::vector<double> h(n, 0.0);
+        for (int l = 0; l < ql; ++l) {
+            const int64_t ttA = (int64_t)2 * l * down_, ttB = ttA + down_;
+            const int nA = (int)(ttA / up_), pA = (int)(ttA % up_), nB = (int)(ttB / up_), pB = (int)(ttB % up_);
+            const int e = (nB - nA) - dmin;
+            for (int j = 0; j < T_; ++j)
+                h[(size_t)j * ql + l] = host_proto_[(size_t)pA + (size_t)j * up_];
+            for (int i = 0; i <= T_; ++i) {
+                const int j = i - 1 + e;
+                h[(size_t)(T_ + i) * ql + l] = j >= 0 && j < T_ ? host_proto_[(size_t)pB + (size_t)j * up_] : 0.0;
+            }
+        }
+        if (pair_taps_.alloc(sizeof(double) * n) != PIPE_HIP_OK)
+            return false;
+        if (hipMemcpy(pair_taps_.p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            pair_taps_.release();
+            return false;
+        }
+        pair_ql_ = ql;
+        return true;
+    }
+
+    // true when the pair kernel took the call
+    bool launch_pair(const ResampleArgs &a, int in_dtype, int out_dtype, bool reg_taps, hipStream_t s)
+    {
+        if (cfg.channels != 2 || !reg_taps || T_ % 4 != 0 || std::getenv("PIPE_HIP_RESAMPLE_NO_PAIR"))
+            return false;
+        const int dmin = down_ / up_;
+        if (dmin > 1)
+            return false;
+        // computing lanes: 2 ql outputs are whole periods of the phase pattern
+        int ql = 0;
+        for (int q = kThreads; q >= 32; --q)
+            if ((2 * q) % up_ == 0) {
+                ql = q;
+                break;
+            }
+        if (ql == 0)
+            return false;
+        if (ql > 192 && (2 * 192) % up_ == 0)
+            ql = 192;  // (three waves: four workgroups share a CU)
+        else if (ql > 192) {
+            for (int q = 192; q >= 32; --q)
+                if ((2 * q) % up_ == 0) {
+                    ql = q;
+                    break;
+                }
+        }
+        const int threads = (ql + 63) / 64 * 64;
+        const size_t es_in = dtype_size(in_dtype);
+        const bool vec_ok = reinterpret_cast<uintptr_t>(a.in) % 16 == 0 &&
+                            (cfg.lines == 1 || ((size_t)a.in_frames * 2 * es_in) % 16 == 0);
+        if (!vec_ok)
+            return false;
+        if (!ensure_pair_taps(ql, dmin))
+            return false;
+        PairArgs t{};
+        t.r = a;
+        t.ql = ql;
+        t.ptaps = static_cast<const double *>(pair_taps_.p);
+        t.adv = (int)((int64_t)2 * ql * down_ / up_);
+        t.steps = kOutTile / (2 * ql) > 0 ? kOutTile / (2 * ql) : 1;
+        for (;; --t.steps) {
+            t.win = t.steps * t.adv + (T_ - 1) + kPairPad + dmin + 3;
+            t.win += t.win & 1;
+            if (t.win / 2 <= kPairVecs * threads || t.steps == 1)
+                break;
+        }
+        if (t.win / 2 > kPairVecs * threads)
+            return false;
+        t.tile_out = 2 * ql * t.steps;
+        t.plane = t.win;
+        t.plane += (16 - t.plane % 32 + 32) % 32;  // plane stride == 16 (mod 32): the channels' planes on distinct banks
+        // tiles start at a multiple of `up` outputs from Start (phase 0): `lead` virtual outputs sit
+        // ahead of the call's first one and are not stored
+        t.lead = (int)(a.out_total % up_);
+        t.nb = (a.out_total - t.lead) / up_ * down_ - a.in_total;
+        t.tiles_per_line = (int)((t.lead + a.out_frames + t.tile_out - 1) / t.tile_out);
+        t.vec_ok = 1;
+        const size_t lds = sizeof(double) * 4 * (size_t)t.plane;
+        if (lds > 64 * 1024)
+            return false;
+        const int64_t ntiles = (int64_t)t.tiles_per_line * cfg.lines;
+        const int64_t slots = 4 * 256;
+        const int64_t per = (ntiles + slots - 1) / slots;
+        const dim3 grid((unsigned)((ntiles + per - 1) / per));
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (timer.pair(&ev_a, &ev_b) != PIPE_HIP_OK)
+            return false;
+#ifdef PH_RS_PROF
+        static DevBuf prof;
+        if (!prof.p && prof.alloc(sizeof(unsigned long long) * 5 * 4 * 4096) != PIPE_HIP_OK)
+            return false;
+        t.prof = static_cast<unsigned long long *>(prof.p);
+#endif
+#define PH_RP(TI, TO, TTV, DM) hipExtLaunchKernelGGL((resample_pair_kernel<TI, TO, TTV, DM>), grid, dim3(threads), lds, s, ev_a, ev_b, 0, t)
+#define PH_RP_T(TI, TO, DM)                 \
+    switch (T_) {                           \
+    case 8: PH_RP(TI, TO, 8, DM); break;    \
+    case 12: PH_RP(TI, TO, 12, DM); break;  \
+    case 16: PH_RP(TI, TO, 16, DM); break;  \
+    case 24: PH_RP(TI, TO, 24, DM); break;  \
+    default: PH_RP(TI, TO, 32, DM); break;  \
+    }
+#define PH_RP_D(TI, TO)      \
+    if (dmin == 0) {         \
+        PH_RP_T(TI, TO, 0)   \
+    } else {                 \
+        PH_RP_T(TI, TO, 1)   \
+    }
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+            PH_RP_D(float, float)
+            last_kernel = "resample_pair_kernel<f32,f32>";
+        } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
+            PH_RP_D(double, double)
+            last_kernel = "resample_pair_kernel<f64,f64>";
+        } else if (in_dtype == PIPE_HIP_F32) {
+            PH_RP_D(float, double)
+            last_kernel = "resample_pair_kernel<f32,f64>";
+        } else {
+            PH_RP_D(double, float)
+            last_kernel = "resample_pair_kernel<f64,f32>";
+        }
+#undef PH_RP_D
+#undef PH_RP_T
+#undef PH_RP
+#ifdef PH_RS_PROF
+        {
+            static int launches = 0;
+            if (++launches == 30) {
+                (void)hipStreamSynchronize(s);
+                const size_t nw = (size_t)grid.x * (threads / 64);
+                std::vector<unsigned long long> h(nw * 5);
+                (void)hipMemcpy(h.data(), t.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+                static const char *names[5] = {"taps + first window", "request next window", "tap loops + stores", "deposit next window", "barrier"};
+                double sum[5] = {}, tot = 0;
+                for (size_t w = 0; w < nw; ++w)
+                    for (int i = 0; i < 5; ++i)
+                        sum[i] += (double)h[w * 5 + i];
+                for (double v : sum)
+                    tot += v;
+                std::fprintf(stderr, "[resampler prof] s_memtime ticks per wave, %zu waves, %lld tiles\n", nw, (long long)ntiles);
+                for (int i = 0; i < 5; ++i)
+                    std::fprintf(stderr, "[resampler prof]   %-22s %9.1f  %5.1f %%\n", names[i], sum[i] / (double)nw, 100.0 * sum[i] / tot);
+                std::fprintf(stderr, "[resampler prof]   %-22s %9.1f\n", "total", tot / (double)nw);
+            }
+        }
+#endif
+        return hipGetLastError() == hipSuccess;
+    }
+
     int T_ = 1, up_ = 1, down_ = 1;
+    std::vector<double> host_proto_;
+    DevBuf pair_taps_;
+    int pair_ql_ = 0;
     DevBuf proto_;
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;

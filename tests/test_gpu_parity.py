@@ -458,8 +458,8 @@ def test_config5_composed_stream_resampler_into_two_input_mix(dtype):
 def test_resample_batch_at_the_bench_shape_windows_against_oracle():
     """The launch bench.py times for configs[4]: 1024 buffers of 4096 x 2 float32 in ONE
     resample_batch call (4.19 M frames in, 4.56 M out), followed by the 2-input mix on the device.
-    The oracle runs the whole stream (it is a 24-tap filter: seconds); start, middle and end windows
-    and a strided sample of the rest are compared bit for bit."""
+    The oracle runs the whole stream (a 24-tap filter: a fraction of a second) and every output frame
+    of both launches is compared bit for bit."""
     T, up, down, F, C, K = 24, 160, 147, 4096, 2, 1024
     proto = synth.resampler_proto(up, down, T)
     n_in = K * F
@@ -471,7 +471,7 @@ def test_resample_batch_at_the_bench_shape_windows_against_oracle():
         p.start()
         n_out = p.resample_batch(d_in, n_in, d_out, cap)
         torch.cuda.synchronize()
-        assert p.kernel_name().startswith("resample_tiled_kernel")
+        assert p.kernel_name().startswith("resample_pair_kernel")   # two adjacent outputs per lane
         # a second launch continues the stream (what the bench's timed loop does)
         d_out2 = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
         n_out2 = p.resample_batch(d_in, n_in, d_out2, cap)
