@@ -576,6 +576,10 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
                        (int64_t)I.D * a.pairs <= ols::kLocalReach &&
                        (lines % P.cus == 0 || lines >= 8 * P.cus);
     a.local = local ? 1 : 0;
+    {
+        const char *e = std::getenv("PIPE_HIP_CHAIN_STAGGER");  // A/B knob
+        a.stagger = e ? std::atoi(e) : 0;
+    }
     if (general) {
         I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
         *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";

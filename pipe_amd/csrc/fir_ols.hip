@@ -420,7 +420,8 @@ bool Plan::supports(int ntaps, int channels)
     (void)channels;
     if (std::getenv("PIPE_HIP_FIR_EXACT"))
         return false;
-    return ntaps >= 16 && ntaps <= 512;
+    // up to 512 taps: one spectrum; 513 .. 4096: partitioned (even channel counts: the 32 x 32 kernel)
+    return ntaps >= 16 && (ntaps <= 512 || (ntaps <= 4096 && channels % 2 == 0 && !std::getenv("PIPE_HIP_FIR_NO_PARTITION")));
 }
 
 // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2 (the kernels take the upper half from
@@ -499,6 +500,13 @@ int Plan::init(int device, const double *taps, int ntaps)
     PH_HIP(hipMemcpy(impl_->tw1.p, t1.data(), sizeof(double) * t1.size(), hipMemcpyHostToDevice));
     PH_HIP(hipMemcpy(impl_->tw2.p, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
     PH_TRY(init_ols32_tables(impl_));
+    if (ntaps > 512) {
+        impl_->P = (ntaps + 511) / 512;
+        impl_->Np = (ntaps + impl_->P - 1) / impl_->P;
+        const size_t pb = sizeof(double) * 2 * (kHalf + 1) * (size_t)impl_->P;
+        PH_TRY(impl_->hpart[0].alloc(pb));
+        PH_TRY(impl_->hpart[1].alloc(pb));
+    }
     PH_TRY(set_taps(taps, nullptr));
     PH_HIP(hipStreamSynchronize(nullptr));
     return PIPE_HIP_OK;
@@ -508,19 +516,32 @@ int Plan::set_taps(const double *taps, hipStream_t s)
 {
     // double-buffered on the device (launches already queued keep the old spectrum), staged
     // through pinned memory and copied on the handle's stream: no device-wide wait
-    const size_t bytes = sizeof(double) * 2 * (kHalf + 1);
-    void *host = nullptr;
-    PH_TRY(impl_->upload.stage(bytes, &host));
-    tap_spectrum(taps, impl_->N, static_cast<double *>(host));
+    const size_t one = sizeof(double) * 2 * (kHalf + 1);
     const int nxt = impl_->cur ^ 1;
-    PH_TRY(impl_->upload.commit(impl_->hperm[nxt].p, bytes, s));
+    void *host = nullptr;
+    if (impl_->P > 1) {  // one spectrum per partition of Np taps (the last one may be shorter)
+        PH_TRY(impl_->upload.stage(one * (size_t)impl_->P, &host));
+        for (int p = 0; p < impl_->P; ++p) {
+            const int first = p * impl_->Np;
+            const int n = impl_->N - first < impl_->Np ? impl_->N - first : impl_->Np;
+            tap_spectrum(taps + first, n > 0 ? n : 0, static_cast<double *>(host) + (size_t)p * 2 * (kHalf + 1));
+        }
+        PH_TRY(impl_->upload.commit(impl_->hpart[nxt].p, one * (size_t)impl_->P, s));
+        impl_->cur = nxt;
+        return PIPE_HIP_OK;
+    }
+    PH_TRY(impl_->upload.stage(one, &host));
+    tap_spectrum(taps, impl_->N, static_cast<double *>(host));
+    PH_TRY(impl_->upload.commit(impl_->hperm[nxt].p, one, s));
     impl_->cur = nxt;
     return PIPE_HIP_OK;
 }
 
+bool Plan::partitioned() const { return impl_->P > 1; }
+
 int64_t Plan::items(int64_t frames, int channels, int lines) const
 {
-    const int L = kM - (impl_->N - 1);
+    const int L = kM - ((impl_->P > 1 ? impl_->Np : impl_->N) - 1);
     return ((frames + L - 1) / L) * ((channels + 1) / 2) * (int64_t)lines;
 }
 
@@ -565,6 +586,12 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
               int64_t frames,
               int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {
+    if (impl_->P > 1) {
+        if (channels % 2 != 0 || reinterpret_cast<uintptr_t>(d_in) % 16 != 0 || reinterpret_cast<uintptr_t>(d_out) % 16 != 0)
+            return PIPE_HIP_EINVAL;  // (the caller asked partitioned_ok() first)
+        return run_ols32p(*impl_, d_in, in_dtype, d_out, out_dtype, hist, hist_new, frames, channels, lines, s, kernel_name,
+                          timer);
+    }
     Args a{};
     a.frames = frames;
     a.hist_new = hist_new;

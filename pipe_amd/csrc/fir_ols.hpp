@@ -29,6 +29,9 @@ public:
             int64_t frames,
             int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer = nullptr);
 
+    // filters above 512 taps run partitioned, on the 32 x 32 kernel only: 16-byte aligned buffers
+    bool partitioned() const;
+
     const Impl &impl() const { return *impl_; }
 
 private:

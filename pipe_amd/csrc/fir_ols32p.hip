@@ -1,0 +1,296 @@
+// Partitioned overlap-save: FIRs of 513 .. 4096 taps on the 32 x 32 transform of fir_ols32.hip.
+//
+// The taps are cut into P partitions of Np <= 512 taps, h = sum_p h_p delayed by p Np frames, so
+//     y[n] = sum_p (h_p * x)[n - p Np].
+// For an output tile of L = 1025 - Np frames, partition p's contribution is the circular convolution of
+// h_p with the 1024-frame window that starts p Np frames EARLIER than partition 0's -- and the valid
+// outputs of every partition sit at the SAME window indices (i >= Np - 1).  Their spectra therefore
+// add: one forward transform per partition, Y = sum_p X_p H_p, ONE inverse transform per tile --
+// P + 1 transforms per L outputs instead of the 2 P of P full passes, and no float64 intermediate
+// through HBM.  A transform needs all 128 of a lane's data registers, so the tile's running sum
+// cannot stay in registers while the next partition's window is transformed: it waits in a per-wave
+// scratch area ([register][lane], so that the accesses coalesce; 32 KB per wave, L2 / Infinity-Cache
+// resident: written once and read once per partition after the first).
+//
+// Same contract as the one-spectrum form: float64 arithmetic, the float32 result within one ulp of
+// the oracle's ordered sum at the filter's full scale (tests/test_gpu_fir_ols.py).
+#include <cstdlib>
+#include <vector>
+
+#include <hip/hip_ext.h>
+
+#include "common.hpp"
+#include "fir_hist.hpp"
+#include "fir_ols.hpp"
+#include "fir_ols_impl.hpp"
+#include "ols32_kernel.hpp"
+
+namespace pipehip {
+namespace ols {
+namespace {
+
+struct ArgsP {
+    Args32 a;            // geometry with H = N - 1 (the whole history), HP = Np - 1, L = 1025 - Np
+    int P, Np;
+    const double2 *hpart;  // [P][kHalf32 + 1] tap spectra of the partitions (scaled by 1/1024)
+    double2 *scratch;      // [waves][32 registers][64 lanes]
+};
+
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(kWaves32 * 64)
+fir_ols32p_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
+                  const double2 *__restrict__ tw_g, const ArgsP t)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2 *tws = reinterpret_cast<double2 *>(smem_raw);         // W1024^(k n), k = 1..31, n = 0..31
+    double *planes = reinterpret_cast<double *>(tws + 31 * 32);   // [waves][2][kPlane32]
+    const Args32 &a = t.a;
+
+    fir_history_carry(in_base, hist_base, static_cast<double *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
+    for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
+        tws[i] = tw_g[32 + i];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane_ = threadIdx.x & 63;
+    const int l5_ = lane_ & 31;
+
+    using In2 = typename Pair<TIn>::type;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nb = (int)gridDim.x;
+    const int xb = nb % 8 == 0 ? ((int)blockIdx.x % 8) * (nb / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int64_t wave_global = (int64_t)wave_u * nb + xb;
+    const int64_t wave_stride = (int64_t)nb * kWaves32;
+    double2 *wave_scratch = t.scratch + ((int64_t)blockIdx.x * kWaves32 + wave_u) * (32 * 64);  // [r][lane]
+    int line = 0, slot = 0;
+    if (wave_global < a.nunits) {
+        line = __builtin_amdgcn_readfirstlane((int)(wave_global / a.upl));
+        slot = __builtin_amdgcn_readfirstlane((int)(wave_global % a.upl));
+    }
+    const unsigned in_step = (unsigned)(32 * a.C * sizeof(TIn));
+    const unsigned out_step = (unsigned)(32 * a.C * sizeof(TOut));
+    auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
+    const int64_t last = a.frames - 1;
+
+    for (int64_t unit = wave_global; unit < a.nunits; unit += wave_stride) {
+        const int item0 = 2 * slot;
+        const int tile0 = __builtin_amdgcn_readfirstlane(item0 / a.pairs);
+        const int pair0 = __builtin_amdgcn_readfirstlane(item0 - tile0 * a.pairs);
+
+        cd lo[16], hi[16];
+        // one partition: FIRST starts the tile's sum, LAST leaves it in the registers for the inverse
+        auto partition = [&](int p, auto first_c, auto last_c) {
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+            // Every per-lane quantity of the loop body is derived again from opaque copies of the lane
+            // indices: whatever is invariant over the partitions would otherwise be computed once per
+            // unit and held in registers through all the transforms, which have none to give (the
+            // library ships no kernel that spills: scripts/check_spills.sh).
+            int l5 = l5_, lane = lane_;
+            asm volatile("" : "+v"(l5), "+v"(lane));
+            const int half = lane >> 5;
+            double *plane = planes + (wave_u * 2 + half) * kPlane32;
+            double *pa = plane + l5;
+            double *pb = plane + 33 * l5;
+            const double2 *__restrict__ twl = tws + l5 - 32;
+            int tile = tile0, pair = pair0 + half;
+            if (pair >= a.pairs) {
+                pair = 0;
+                tile = tile0 + 1;
+            }
+            const bool valid = item0 + half < a.ipl;
+            const int c0 = 2 * pair;
+            // ---- partition p's window: it starts p Np frames before partition 0's ------------------
+            const int64_t fr00 = (int64_t)tile0 * a.L - a.HP - (int64_t)p * t.Np;  // half 0's first window frame
+            if (fr00 >= 0) {
+                const TIn *base = in_base + (int64_t)line * a.line_stride + fr00 * a.C;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(base), 0, bytes31((a.frames - fr00) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+                unsigned v0 = valid ? (unsigned)((((tile - tile0) * a.L + l5) * a.C + c0) * (int)sizeof(TIn)) : kOut32;
+                asm volatile("" : "+v"(v0));  // (the 32 lane offsets are made per partition, not kept across the transforms)
+                In2 pf[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
+            } else {
+                // the window reaches back into the history (N - 1 frames deep)
+                const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
+                const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+                const int64_t fr0 = (int64_t)tile * a.L - a.HP - (int64_t)p * t.Np;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int64_t g = fr0 + l5 + 32 * r;
+                    double re = 0.0, im = 0.0;
+                    if (valid) {
+                        if (g >= 0) {
+                            if (g <= last) {
+                                re = (double)in[g * a.C + c0];
+                                im = (double)in[g * a.C + c0 + 1];
+                            }
+                        } else if (g >= -(int64_t)a.H) {
+                            re = hist[(g + a.H) * a.C + c0];
+                            im = hist[(g + a.H) * a.C + c0 + 1];
+                        }
+                    }
+                    PH_NAT(r) = cd{re, im};
+                }
+            }
+            ols32_forward(lo, hi, pa, pb, twl);
+            __builtin_amdgcn_sched_barrier(0);  // the product's loads and addresses stay out of the transform's registers
+            // ---- times H_p: lane k2 = l5, register k1 (split layout) holds X[32 k1 + l5]; the upper
+            //      half of the spectrum is the conjugate mirror (real taps) ----------------------------
+            // Four registers at a time, fenced: all 32 spectrum entries (and 32 pieces of the running
+            // sum) requested at once would sit in 256 registers next to the tile's 128.
+            // (The per-lane addresses of the spectrum and of the scratch area are invariant over both
+            // loops; hoisted out they would sit in ~130 registers through the transform, which has
+            // none to give.  Opaque copies of the lane indices keep them inside.)
+            const int l5o = l5;
+            const double2 *__restrict__ hp = t.hpart + (size_t)p * (kHalf32 + 1);
+            double2 *__restrict__ mine = wave_scratch + lane;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                double2 h[4], sum[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k1 = 4 * g + i;
+                    h[i] = k1 < 16 ? hp[32 * k1 + l5o] : hp[1024 - 32 * k1 - l5o];
+                }
+                // (FIRST / LAST are compile-time: a run-time branch around these loads made the compiler keep
+                // two versions of the loop body's registers -- 51 spilled)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    sum[i] = FIRST ? double2{0.0, 0.0} : mine[(4 * g + i) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k1 = 4 * g + i;
+                    const cd w{h[i].x, k1 < 16 ? h[i].y : -h[i].y};
+                    cd v = cmul(PH_SPL(k1), w);
+                    v.re += sum[i].x;
+                    v.im += sum[i].y;
+                    if constexpr (LAST)
+                        PH_SPL(k1) = v;
+                    else
+                        mine[k1 * 64] = double2{v.re, v.im};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        partition(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+        for (int p = 1; p + 1 < t.P; ++p)
+            partition(p, std::false_type{}, std::false_type{});
+        partition(t.P - 1, std::false_type{}, std::true_type{});
+        // the next unit's coordinates (uniform)
+        const int cur_line = line;
+        slot += a.d_slot;
+        if (slot >= a.upl) {
+            slot -= a.upl;
+            ++line;
+        }
+        line += a.d_line;
+
+        int l5 = l5_, lane = lane_;
+        asm volatile("" : "+v"(l5), "+v"(lane));
+        const int half = lane >> 5;
+        double *plane = planes + (wave_u * 2 + half) * kPlane32;
+        double *pa = plane + l5;
+        double *pb = plane + 33 * l5;
+        const double2 *__restrict__ twl = tws + l5 - 32;
+        int tile = tile0, pair = pair0 + half;
+        if (pair >= a.pairs) {
+            pair = 0;
+            tile = tile0 + 1;
+        }
+        const bool valid = item0 + half < a.ipl;
+        const int c0 = 2 * pair;
+        ols32_inverse_plain(lo, hi, pa, pb, twl);
+
+        // ---- store the valid part: window index i >= HP is frame tile L + i - HP ---------------------
+        {
+            const int64_t t00 = (int64_t)tile0 * a.L;
+            TOut *base = out_base + (int64_t)cur_line * a.line_stride + t00 * a.C;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                base, 0, bytes31((a.frames - t00) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
+            const int o0 = (((tile - tile0) * a.L + l5 - a.HP) * a.C + c0) * (int)sizeof(TOut);
+            const int i0 = valid ? l5 - a.HP : -2048;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int off = o0 + r * (int)out_step;
+                buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+            }
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+int launch32p(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, ArgsP t, hipStream_t s,
+              KernelTimer *timer)
+{
+    auto kfn = fir_ols32p_kernel<TIn, TOut>;
+    const size_t lds = sizeof(double2) * (31 * 32) + sizeof(double) * (size_t)kPlane32 * 2 * kWaves32;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    const int64_t resident = I.cus;  // one 512-thread workgroup per CU
+    const int64_t wanted = (t.a.nunits + kWaves32 - 1) / kWaves32;
+    const unsigned grid = (unsigned)(wanted < resident ? wanted : resident);
+    const int64_t stride = (int64_t)grid * kWaves32;
+    t.a.d_slot = (int)(stride % t.a.upl);
+    t.a.d_line = (int)(stride / t.a.upl);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (timer)
+        PH_TRY(timer->pair(&ev_a, &ev_b));
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
+                          static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw32.p), t);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
+}  // namespace
+
+int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist,
+               double *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
+               KernelTimer *timer)
+{
+    ArgsP t{};
+    Args32 &a = t.a;
+    a.frames = frames;
+    a.hist_new = hist_new;
+    a.line_stride = frames * channels;
+    a.C = channels;
+    a.N = I.N;
+    a.H = I.N - 1;
+    a.HP = I.Np - 1;
+    a.L = kM32 - a.HP;
+    a.pairs = channels / 2;
+    a.lines = lines;
+    a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
+    a.ipl = a.tiles_per_line * a.pairs;
+    a.upl = (a.ipl + 1) / 2;
+    a.nunits = (int64_t)a.upl * lines;
+    t.P = I.P;
+    t.Np = I.Np;
+    t.hpart = static_cast<const double2 *>(I.hpart[I.cur].p);
+    const size_t need = sizeof(double2) * 32 * 64 * (size_t)kWaves32 * (size_t)I.cus;
+    if (I.scratch.bytes < need)
+        PH_TRY(I.scratch.alloc(need));
+    t.scratch = static_cast<double2 *>(I.scratch.p);
+    if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+        *kernel_name = "fir_ols_kernel<f32,f32,32x32,partitioned>";
+        return launch32p<float, float>(I, d_in, d_out, hist, t, s, timer);
+    }
+    if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
+        *kernel_name = "fir_ols_kernel<f64,f32,32x32,partitioned>";
+        return launch32p<double, float>(I, d_in, d_out, hist, t, s, timer);
+    }
+    if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
+        *kernel_name = "fir_ols_kernel<f32,f64,32x32,partitioned>";
+        return launch32p<float, double>(I, d_in, d_out, hist, t, s, timer);
+    }
+    *kernel_name = "fir_ols_kernel<f64,f64,32x32,partitioned>";
+    return launch32p<double, double>(I, d_in, d_out, hist, t, s, timer);
+}
+
+}  // namespace ols
+}  // namespace pipehip

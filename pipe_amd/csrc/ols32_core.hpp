@@ -8,6 +8,14 @@
 namespace pipehip {
 namespace ols {
 
+// Ablation builds for the energy table (scripts/build_ablate_lib.sh fir_ols32 PH_OLS_ABLATE ...; never
+// the shipped library; the results are WRONG, the instruction streams are what is measured):
+// bit 0: the two exchanges through the LDS plane become register copies; bit 1: the twiddle table and
+// the tap spectrum are one value read once instead of 94 LDS reads per unit.
+#ifndef PH_OLS_ABLATE
+#define PH_OLS_ABLATE 0
+#endif
+
 constexpr int kM32 = 1024;
 constexpr int kHalf32 = 513;          // H[0..512] (+1 pad)
 constexpr int kPlane32 = 32 * 33;     // doubles per item exchange plane (stride 33)
@@ -246,6 +254,16 @@ __device__ __forceinline__ void ols32_transform(cd (&lo)[16], cd (&hi)[16], doub
 {
         // one exchange through the item's plane, real parts then imaginary parts:
         // WR(k): address the value of register k goes to;  RD(k): where register k comes from
+#if PH_OLS_ABLATE & 1
+#define PH_EXCHANGE(WREG, WADDR, RREG, RADDR)                 \
+    do {                                                      \
+        cd t_[32];                                            \
+        _Pragma("unroll") for (int k = 0; k < 32; ++k)        \
+            t_[k] = WREG(k);                                  \
+        _Pragma("unroll") for (int k = 0; k < 32; ++k)        \
+            RREG(k) = t_[k];                                  \
+    } while (0)
+#else
 #define PH_EXCHANGE(WREG, WADDR, RREG, RADDR)                 \
     do {                                                      \
         double re_[32];                                       \
@@ -262,25 +280,33 @@ __device__ __forceinline__ void ols32_transform(cd (&lo)[16], cd (&hi)[16], doub
             RREG(k) = cd{re_[k], RADDR(k)};                   \
         wave_fence();                                         \
     } while (0)
+#endif
 
         // the inter-pass twiddles W1024^(n1 k2) and the tap spectrum are not applied on their own:
         // they ride into the next 32-point DFT as pending factors.  The table is symmetric in
         // (register, lane), so the twiddles may sit on either side of the exchange: after it.
+#if PH_OLS_ABLATE & 2
+        double2 one_ = twl[32];
+        asm volatile("" : "+v"(one_.x), "+v"(one_.y));  // (a register value the compiler knows nothing about)
+#define PH_TAB(expr) one_
+#else
+#define PH_TAB(expr) (expr)
+#endif
         const auto tw_fwd = [&](int k) {
-            const double2 t = twl[32 * k];
+            const double2 t = PH_TAB(twl[32 * k]);
             return cd{t.x, t.y};
         };
         const auto tw_inv = [&](int k) {
-            const double2 t = twl[32 * k];
+            const double2 t = PH_TAB(twl[32 * k]);
             return cd{t.x, -t.y};
         };
         // tap spectrum (scaled by 1/M) at k = 32 k1 + l5; upper half read as the conjugate mirror
         const auto taps_at = [&](int k1) {
             if (k1 < 16) {
-                const double2 h = hlo[32 * k1];
+                const double2 h = PH_TAB(hlo[32 * k1]);
                 return cd{h.x, h.y};
             }
-            const double2 h = hhi[1024 - 32 * k1];
+            const double2 h = PH_TAB(hhi[1024 - 32 * k1]);
             return cd{h.x, -h.y};
         };
 
@@ -294,8 +320,45 @@ __device__ __forceinline__ void ols32_transform(cd (&lo)[16], cd (&hi)[16], doub
         PH_EXCHANGE(PH_NAT, PH_ROW, PH_SPL, PH_COL);   // (lane k2, reg n1) -> (lane n1, reg k2 split)
         dft32_dit_rt<+1, true>(lo, hi, tw_inv);        // conj W1024^(n1 k2), then over k2 -> n2 (natural)
 
-#undef PH_EXCHANGE
 }
+
+// The two halves of the transform on their own, for the partitioned form (fir_ols32p.hip: filters of
+// 513 .. 4096 taps as several <= 512-tap spectra whose products are summed in the frequency domain).
+//   forward : window (natural) -> spectrum, lane k2, register k1 in split layout: X[32 k1 + k2]
+//   inverse : spectrum (split)  -> circular result (natural); no tap factor rides in
+__device__ __forceinline__ void ols32_forward(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb,
+                                              const double2 *__restrict__ twl)
+{
+    const auto tw_fwd = [&](int k) {
+        const double2 t = twl[32 * k];
+        return cd{t.x, t.y};
+    };
+    dft32_dif<-1>(lo, hi);
+    PH_EXCHANGE(PH_SPL, PH_COL, PH_NAT, PH_ROW);
+    dft32_dif_rt<-1>(lo, hi, tw_fwd);
+}
+__device__ __forceinline__ void ols32_inverse_plain(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb,
+                                                    const double2 *__restrict__ twl)
+{
+    const auto tw_inv = [&](int k) {
+        const double2 t = twl[32 * k];
+        return cd{t.x, -t.y};
+    };
+    // over k1 -> n1 without factors: X[2m] = lo[m], X[2m + 1] = hi[m] -> x[n] = lo[n], x[16 + n] = hi[n]
+    dft16p<+1>(lo, 0, 0);
+    dft16p<+1>(hi, 0, 0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        cd a, b;
+        bf<+1>(lo[n], pend_none(), hi[n], pend_w32<+1>(n), a, b);
+        lo[n] = a;
+        hi[n] = b;
+    }
+    PH_EXCHANGE(PH_NAT, PH_ROW, PH_SPL, PH_COL);
+    dft32_dit_rt<+1, true>(lo, hi, tw_inv);
+}
+#undef PH_EXCHANGE
+#undef PH_TAB
 
 }  // namespace ols
 }  // namespace pipehip

@@ -49,6 +49,7 @@ struct Args32 {
     int pairs, lines, tiles_per_line;
     int ipl, upl;         // items per Line (tiles x pairs); units (item pairs) per Line
     int local;            // fused chain: every Line's tiles run in ONE workgroup, records in LDS (below)
+    int stagger;          // fused chain: the second wave of every SIMD starts this many s_sleep(127) late
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
     void *hist_new;       // float64 elements (S = 0), the stream's float32 (fused chain, S > 0)
@@ -708,6 +709,14 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, l5 = lane & 31;
+    if constexpr (S > 0) {
+        // The two waves of a SIMD (w and w + 4) out of step by part of a unit: one wave's epilogue --
+        // chains of dependent operations and round trips -- then runs under the other's dense transform
+        // instead of beside its epilogue.
+        if (a.stagger > 0 && __builtin_amdgcn_readfirstlane(wave) >= kWaves32 / 2)
+            for (int i = 0; i < a.stagger; ++i)
+                __builtin_amdgcn_s_sleep(127);
+    }
     double *plane = planes + (wave * 2 + half) * kPlane32;
     double *pa = plane + l5;       // (row r, this lane's column): pa[33 r]
     double *pb = plane + 33 * l5;  // (this lane's row, column c): pb[c]

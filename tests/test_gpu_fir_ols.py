@@ -57,6 +57,30 @@ def run_batch(taps, x, F, K, lines, exact):
         return torch.cat(outs, dim=-2).cpu().numpy(), name
 
 
+@pytest.mark.parametrize("channels,ntaps,F,K", [(2, 1024, 1024, 24), (2, 513, 1024, 24), (4, 700, 512, 40), (2, 4096, 4096, 8),
+                                                 (8, 1500, 2048, 6), (2, 2049, 300, 70)])
+def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, monkeypatch):
+    """513 .. 4096 taps: several <= 512-tap spectra whose products are summed in the frequency domain
+    (fir_ols32p.hip).  Same contract as the one-spectrum form; two launches, so the N - 1 frames of
+    history (deeper than a tile) carry across; the direct form on the same data stays bit-exact."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines = 2
+    taps = synth.fir_lowpass_taps(ntaps, fc=0.11, f32_rounded=True)
+    x = np.stack([synth.samples(synth.line_seed(80 + l), 0, K * F * channels, np.float32).reshape(K * F, channels)
+                  for l in range(lines)])
+    got, name = run_batch(taps, x, F, K, lines, exact=False)
+    assert "partitioned" in name, name
+    ref, name2 = run_batch(taps, x, F, K, lines, exact=True)
+    assert "fir_direct_kernel" in name2
+    floor = 2.0 ** -24 * np.abs(taps).sum() * 1.0
+    for l in range(lines):
+        want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(K * F, channels)
+        assert np.array_equal(ref[l], want.astype(np.float32))
+        d = ulp_diff_f32(got[l], want, floor)
+        assert d.max() <= 1.0, f"line {l}: max {d.max()} ulp at {np.unravel_index(d.argmax(), d.shape)}"
+        assert np.mean(got[l] != want.astype(np.float32)) < 1e-4
+
+
 @pytest.mark.parametrize("channels,ntaps", [(2, 256), (2, 64), (2, 511), (4, 256), (3, 256), (1, 128)])
 def test_ols_within_one_ulp_of_oracle_and_of_direct_form(channels, ntaps, monkeypatch):
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")  # take the FFT form even for this small batch
