@@ -40,6 +40,10 @@ type Batch struct {
 	frames    []C.int32_t
 	written   []C.int32_t
 	live      []bool
+	// StartFunc bookkeeping (the C++ mirror's HipBatch::start): slots started and not flushed, and
+	// whether a pass has run since the whole handle was last started
+	started int
+	dirty   bool
 }
 
 // BatchedChain: stages as in Chain; Allocator(slot) is the allocator of Line `slot`.
@@ -47,11 +51,22 @@ func BatchedChain(o Options, lines int, stages ...*Stage) *Batch {
 	return &Batch{stages: stages, lines: lines, opts: o}
 }
 
-// BatchProcessor is what the stage-major executor looks for on a Processor (an interface the
-// patch adds to package pipe): Processors with the same Group advance together.
-type BatchProcessor interface {
-	Group() *Batch
-	Slot() int
+// Slots implements pipe.BatchGroup (../pipe_patch/run_batched.go).
+func (b *Batch) Slots() int { return b.lines }
+
+// Close releases the shared handle and the slots' pinned buffers.
+func (b *Batch) Close() {
+	if b.p != nil {
+		C.pipe_hip_destroy(b.p)
+		b.p = nil
+	}
+	for i := range b.inP {
+		C.pipe_hip_host_free(b.inP[i])
+	}
+	for i := range b.outP {
+		C.pipe_hip_host_free(b.outP[i])
+	}
+	b.inP, b.outP, b.in, b.out = nil, nil, nil, nil
 }
 
 func (b *Batch) bind(mctx mutable.Context, bufferSize int, in pipe.SignalProperties) error {
@@ -67,17 +82,20 @@ func (b *Batch) bind(mctx mutable.Context, bufferSize int, in pipe.SignalPropert
 		return err
 	}
 	b.p, b.bufferSize, b.chans, b.mctx = chain, bufferSize, in.Channels, mctx
+	runtime.SetFinalizer(b, (*Batch).Close)
 	n := bufferSize * in.Channels
 	for i := 0; i < b.lines; i++ {
 		hi, pi, err := pinned(n)
 		if err != nil {
-			return err
-		}
-		ho, po, err := pinned(n)
-		if err != nil {
+			b.Close()
 			return err
 		}
 		b.in, b.inP = append(b.in, hi), append(b.inP, pi)
+		ho, po, err := pinned(n)
+		if err != nil {
+			b.Close()
+			return err
+		}
 		b.out, b.outP = append(b.out, ho), append(b.outP, po)
 	}
 	b.frames = make([]C.int32_t, b.lines)
@@ -95,16 +113,35 @@ func (b *Batch) Allocator(slot int) pipe.ProcessorAllocatorFunc {
 		}
 		return pipe.Processor{
 			SignalProperties: in, // a fixed-rate chain keeps rate and channels
-			// only THIS Line's slot starts from silence: a Line added to a running pipe (pipe.go:260-300)
-			// must not reset the Lines that are already streaming through the same handle
+			// The Lines of a group start together before the first pass (run.go:76-85): the first of
+			// them starts the WHOLE handle once, the others find it started.  A Line added to a
+			// running pipe (pipe.go:260-300) must not reset the Lines already streaming through the
+			// same handle: its slot alone starts from silence.
 			StartFunc: func(context.Context) error {
-				return status(C.pipe_hip_start_lines(b.p, C.int32_t(slot), 1), "start_lines")
+				var st C.int
+				switch {
+				case b.started == 0:
+					st = C.pipe_hip_start(b.p)
+					b.dirty = false
+				case b.dirty:
+					st = C.pipe_hip_start_lines(b.p, C.int32_t(slot), 1)
+				}
+				if err := status(st, "start"); err != nil {
+					return err // (a failed StartFunc gets no FlushFunc: run.go:54-62)
+				}
+				b.started++
+				return nil
 			},
-			FlushFunc:        func(context.Context) error { return status(C.pipe_hip_flush(b.p), "flush") },
+			FlushFunc: func(context.Context) error {
+				if b.started > 0 {
+					b.started--
+				}
+				return status(C.pipe_hip_flush(b.p), "flush")
+			},
 			ProcessFunc: func(signal.Floating, signal.Floating) (int, error) {
 				return 0, errors.New("hip.Batch: run the Lines with pipe.RunBatched")
 			},
-			// Batch: b, BatchSlot: slot   <- the two fields the patch adds to pipe.Processor
+			Batch: b, BatchSlot: slot, // the two fields ../pipe_patch adds to pipe.Processor
 		}, nil
 	}
 }
@@ -113,6 +150,7 @@ func (b *Batch) Allocator(slot int) pipe.ProcessorAllocatorFunc {
 // of the Lines that delivered a buffer this pass (nil: the Line has ended).  Every Line advances
 // by exactly its own frames (a short read mid-stream included, pipe.go:404-406).
 func (b *Batch) ProcessLines(ins, outs []signal.Floating) ([]int, error) {
+	b.dirty = true
 	inPtrs := make([]unsafe.Pointer, b.lines)
 	outPtrs := make([]unsafe.Pointer, b.lines)
 	for i := 0; i < b.lines; i++ {

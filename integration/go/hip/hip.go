@@ -123,14 +123,18 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 			C.pipe_hip_destroy(p)
 			return pipe.Processor{}, err
 		}
+		// the finalizer goes on BEFORE anything else can fail: a failed pinned allocation below
+		// must not leak the device handle (Close frees whatever exists, nil pointers included)
 		s.p, s.mctx, s.outChannels = p, mctx, int(ch)
+		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
 		if s.inH, s.inP, err = pinned(bufferSize * in.Channels); err != nil {
+			s.Close()
 			return pipe.Processor{}, err
 		}
 		if s.outH, s.outP, err = pinned(bufferSize * int(ch)); err != nil {
+			s.Close()
 			return pipe.Processor{}, err
 		}
-		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
 		return pipe.Processor{
 			// the stage's OUTPUT properties: they size the out pool (pipe.go:418) and are the
 			// next stage's input (line.go:75)
@@ -164,10 +168,12 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 func (s *Stage) Close() {
 	if s.p != nil {
 		C.pipe_hip_destroy(s.p)
-		C.pipe_hip_host_free(s.inP)
-		C.pipe_hip_host_free(s.outP)
 		s.p = nil
 	}
+	// (pipe_hip_host_free accepts NULL: an allocator that failed half-way leaves one of them nil)
+	C.pipe_hip_host_free(s.inP)
+	C.pipe_hip_host_free(s.outP)
+	s.inP, s.outP, s.inH, s.outH = nil, nil, nil, nil
 }
 
 // ---- allocators -----------------------------------------------------------------------------
