@@ -95,7 +95,7 @@ def usable_cores() -> int:
 
 
 KERNEL_SOURCES = ("ols_math.hpp", "ols32_core.hpp", "ols32_kernel.hpp", "fir_hist.hpp", "fir_ols32.hip",
-                  "fir_ols_impl.hpp", "chain_fused.hip", "fir_ols.hip", "Makefile")
+                  "fir_ols_impl.hpp", "chain_fused.hip", "fir_ols.hip", "resampler.hip", "Makefile")
 
 
 def csrc_sha16() -> str:

@@ -468,7 +468,7 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
             PH_HIP(hipMemcpy(h.data(), fa.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
             static const char *names[ols::kFuseProfPhases] = {
                 "window + FIR transform", "to segments + pass 1", "scan", "publish A", "look-back", "publish P",
-                "pass 3", "back to natural", "last-tile pass 3 + back", "stores"};
+                "pass 3", "back to natural", "last-tile pass 3 + back", "stores", "lookback: own state", "lookback: wait", "-"};
             double sum[ols::kFuseProfPhases] = {}, tot = 0;
             for (size_t w = 0; w < (size_t)kWaves32 * grid; ++w)
                 for (int i = 0; i < ols::kFuseProfPhases; ++i)
@@ -481,6 +481,18 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
                 std::fprintf(stderr, "[fused prof]   %-26s %9.1f  %5.1f %%\n", names[i], sum[i] / (double)a.nunits,
                              100.0 * sum[i] / tot);
             std::fprintf(stderr, "[fused prof]   %-26s %9.1f\n", "total", tot / (double)a.nunits);
+            // per wave index of the workgroup (averaged over the workgroups): who waits for whom
+            for (int w = 0; w < kWaves32; ++w) {
+                double ph[ols::kFuseProfPhases] = {};
+                for (unsigned b = 0; b < grid; ++b)
+                    for (int i = 0; i < ols::kFuseProfPhases; ++i)
+                        ph[i] += (double)h[((size_t)b * kWaves32 + w) * ols::kFuseProfPhases + i];
+                double t = 0;
+                for (double v : ph)
+                    t += v;
+                std::fprintf(stderr, "[fused prof]   wave %d: transform %8.0f  segments %6.0f  wait %7.0f  pass3 %6.0f  stores %6.0f  total %8.0f\n", w,
+                             ph[0] / grid, ph[1] / grid, ph[11] / grid, ph[6] / grid, ph[9] / grid, t / grid);
+            }
         }
     }
 #endif

@@ -19,7 +19,7 @@ constexpr int kWaves32 = 8;             // waves per workgroup = per CU
 // -DPH_FUSE_PROF: per-phase s_memtime sums of every wave of the fused kernel (a debug build of
 // the library, scripts/build_prof_lib.sh; never the shipped one)
 #ifdef PH_FUSE_PROF
-constexpr int kFuseProfPhases = 10;
+constexpr int kFuseProfPhases = 13;
 #define PH_FSTAMP(i)                                                          \
     do {                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                    \
@@ -391,6 +391,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
             own_read<NV>(fa.own + series * (2 * 2 * NV), fa.epoch, own);
     }
 
+    PH_FSTAMP(10);  // look-back: own state / matrix requests
     double sr[N2], si[N2];  // start state of the tile
 #pragma unroll
     for (int j = 0; j < N2; ++j)
@@ -466,6 +467,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                 }
             }
         }
+        PH_FSTAMP(11);  // look-back: waiting for the predecessors' records
         double zero[N2], vr[N2], vi[N2];
 #pragma unroll
         for (int j = 0; j < N2; ++j)

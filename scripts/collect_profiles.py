@@ -26,8 +26,9 @@ for c in (1, 2, 3):
     json.loads(line)
     open(os.path.join(dst, f"{tag}_c{c}_bench.json"), "w").write(line + "\n")
     e = json.load(open(os.path.join(d, "pmc_entry.json")))
-    e["config"] = c
-    entries.append(e)
+    for one in (e if isinstance(e, list) else [e]):
+        one["config"] = c if one is (e[0] if isinstance(e, list) else e) else ("3 (c4_chain of the default line)" if "chain" in one["bench_kernel"] else "4 (c5 of the default line)")
+        entries.append(one)
 d = os.path.join(src, f"{tag}_configs")
 if os.path.isdir(d):
     shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, f"{tag}_configs_summary.txt"))

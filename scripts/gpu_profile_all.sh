@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r02}
 for c in 1 2 3; do
-  bash scripts/profile.sh ${TAG}_c$c --config $c > /dev/null 2>&1
+  PMC_SECONDARY=$([ $c = 1 ] && echo 1 || echo 0) bash scripts/profile.sh ${TAG}_c$c --config $c > /dev/null 2>&1
   find gpurun_out/prof/${TAG}_c$c -name '*.db' -delete
   find gpurun_out/prof/${TAG}_c$c -type d -empty -delete
   tail -5 gpurun_out/prof/${TAG}_c$c/pmc_entry.json

@@ -28,6 +28,9 @@ else:
     pat = re.escape(kname.split("<")[0])
 
 
+global_pat = [pat]
+
+
 def mean_counter(sub, counter):
     vals = []
     for p in glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True):
@@ -35,26 +38,46 @@ def mean_counter(sub, counter):
         per = {}
         for name, cname, val, disp in db.execute(
                 "select name, counter_name, counter_value, dispatch_id from pmc_events"):
-            if cname == counter and re.search(pat, name):
+            if cname == counter and re.search(global_pat[0], name):
                 per[disp] = per.get(disp, 0.0) + val   # one row per shader engine / XCC: sum them
         vals += list(per.values())
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE")
-write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE")
+def entry_for(kname, pat, workload, alg_bytes):
+    """HBM bytes per launch of the dispatches whose device kernel name matches `pat`."""
+    global_pat[0] = pat
+    fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE")
+    write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE")
+    e = {
+        "bench_kernel": kname,
+        "device_kernel_regex": pat,
+        "workload": workload,
+        "csrc_sha16": B.csrc_sha16(),
+        "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "dispatches": [nf, nw],
+        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM; calibrated for 16 / 8 / 4 B per lane loads in "
+                      "profiles/r03_fetch_calibration.txt: 0.500 - 0.508 of the bytes moved), WRITE_SIZE x1 (1.000 there)",
+        "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024) if fetch_kb and write_kb else None,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "source": f"scripts/profile.sh {os.path.basename(out.rstrip('/'))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+    }
+    if e["hbm_bytes_per_launch"]:
+        e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / alg_bytes, 4)
+    return e
+
+
 import bench as B  # noqa: E402  (csrc_sha16)
-entry = {
-    "bench_kernel": kname,
-    "device_kernel_regex": pat,
-    "workload": bench["config"]["workload"],
-    "csrc_sha16": B.csrc_sha16(),
-    "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "dispatches": [nf, nw],
-    "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM): 64 B counted per 128 B request",
-    "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024) if fetch_kb and write_kb else None,
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "source": f"scripts/profile.sh {os.path.basename(out.rstrip('/'))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-}
-if entry["hbm_bytes_per_launch"]:
-    entry["traffic_over_algorithmic"] = round(entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"], 4)
-print(json.dumps(entry, indent=1))
+entries = [entry_for(kname, pat, bench["config"]["workload"], bench["roofline"]["algorithmic_bytes_per_launch"])]
+# the BASELINE configs[3] / configs[4] objects of the default line (when the PMC passes ran them too)
+try:
+    full = json.loads(open(os.path.join(out, "pmc_fetch.json")).read().strip().splitlines()[-1])
+except (OSError, ValueError, IndexError):
+    full = {}
+c4 = full.get("c4_chain")
+if c4:
+    entries.append(entry_for(c4["kernel"], r"fir_ols32_kernel<float, float, [12]", c4["workload"], c4["algorithmic_bytes_per_launch"]))
+c5 = (full.get("c5_resampler_mix") or {}).get("resampler")
+if c5:
+    entries.append(entry_for(c5["kernel"], r"resample_(pair|tiled)_kernel<", full["c5_resampler_mix"]["workload"],
+                             c5["algorithmic_bytes_per_launch"]))
+print(json.dumps(entries if len(entries) > 1 else entries[0], indent=1))
