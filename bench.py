@@ -378,7 +378,7 @@ def run_rank(args, rank, world, local, sync, launch):
 
     # SURVEY.md 8(d) "C3" shape next to the headline (N = 1, config 1 only): 64 Lines x 256 buffers,
     # after a warm-up long enough to be at steady state (short launches after an idle period read
-    # the clock ramp)
+    # the clock ramp, docs/NOTEBOOK.md section 4)
     if cfg == 1 and world == 1 and not args.no_secondary and args.dtype == "f32":
         del d_out
         L2, K2 = 64, 256

@@ -93,7 +93,8 @@ typedef struct pipe_hip_config {
 /* ---- allocators: the body of a ProcessorAllocatorFunc (line.go:26-30) ------ */
 /* y = x * gain */
 int pipe_hip_gain_create(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out);
-/* direct-form FIR, same taps for every channel; 1 <= ntaps <= 4096 */
+/* FIR, same taps for every channel; 1 <= ntaps <= 4096 (ordered direct form; large float32
+ * batches take the overlap-save form, above 512 taps partitioned: PIPE_HIP_PARAM_EXACT) */
 int pipe_hip_fir_create(const pipe_hip_config *cfg, const double *taps, int32_t ntaps,
                         pipe_hip_processor **out);
 /* DF2T biquad cascade; coeffs = nsections x {b0,b1,b2,a1,a2}; 1 <= nsections <= 8 */
@@ -196,7 +197,11 @@ int pipe_hip_chain_set_param(pipe_hip_processor *chain, int32_t stage, int32_t p
  * handle's own stream); state carries to the next call exactly as if the frames
  * had been processed buffer by buffer.  For the resampler *out_frames (may be
  * NULL otherwise) receives the frames written per Line and d_out must hold
- * out_cap_frames per Line. */
+ * out_cap_frames per Line.  These calls return before the device has run them: a
+ * device-side failure (the fused chain kernel giving up on a predecessor tile that
+ * never shows up, e.g. another process holding half the CUs) is reported as
+ * PIPE_HIP_EHIP by the NEXT synchronous entry on the handle -- pipe_hip_process,
+ * pipe_hip_collect, pipe_hip_process_lines[_pinned] or pipe_hip_flush. */
 int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,
                            int64_t frames_per_line, void *stream);
 int pipe_hip_resample_batch(pipe_hip_processor *p, const void *d_in, int64_t in_frames_per_line,

@@ -31,7 +31,7 @@ else:
 global_pat = [pat]
 
 
-def mean_counter(sub, counter):
+def mean_counter(sub, counter, largest_only=False):
     vals = []
     for p in glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True):
         db = sqlite3.connect(p)
@@ -41,14 +41,17 @@ def mean_counter(sub, counter):
             if cname == counter and re.search(global_pat[0], name):
                 per[disp] = per.get(disp, 0.0) + val   # one row per shader engine / XCC: sum them
         vals += list(per.values())
+    if largest_only and vals:  # the bench kernel's own launches: the same kernel also runs the smaller c3_shape
+        top = max(vals)
+        vals = [v for v in vals if v >= 0.5 * top]
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def entry_for(kname, pat, workload, alg_bytes):
+def entry_for(kname, pat, workload, alg_bytes, largest_only=False):
     """HBM bytes per launch of the dispatches whose device kernel name matches `pat`."""
     global_pat[0] = pat
-    fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE")
-    write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE")
+    fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE", largest_only)
+    write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE", largest_only)
     e = {
         "bench_kernel": kname,
         "device_kernel_regex": pat,
@@ -67,7 +70,7 @@ def entry_for(kname, pat, workload, alg_bytes):
 
 
 import bench as B  # noqa: E402  (csrc_sha16)
-entries = [entry_for(kname, pat, bench["config"]["workload"], bench["roofline"]["algorithmic_bytes_per_launch"])]
+entries = [entry_for(kname, pat, bench["config"]["workload"], bench["roofline"]["algorithmic_bytes_per_launch"], largest_only=True)]
 # the BASELINE configs[3] / configs[4] objects of the default line (when the PMC passes ran them too)
 try:
     full = json.loads(open(os.path.join(out, "pmc_fetch.json")).read().strip().splitlines()[-1])
