@@ -67,6 +67,8 @@ def parse():
                     help="N > 1 as threads of ONE process (one per GPU, no process group) instead of N processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config[2]-shape line at N = 1")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc passes of this command (N = 1)")
     ap.add_argument("--cpu-buffers", type=int, default=4096,
                     help="buffers of the same workload timed on the CPU (bounded sample)")
     return ap.parse_args()
@@ -123,6 +125,69 @@ def committed_traffic(kernel: str, algorithmic_bytes: int):
                 and entry.get("algorithmic_bytes_per_launch") == algorithmic_bytes):
             return entry.get("hbm_bytes_per_launch")
     return None
+
+
+# device kernel names (rocprofv3) of the kernels this file reports traffic for
+PMC_KERNELS = {
+    "main_ols": r"fir_ols32_kernel<float, float, 0",
+    "main_chain": r"fir_ols32_kernel<float, float, [12]",
+    "c4_chain": r"fir_ols32_kernel<float, float, [12]",
+    "c5_resampler": r"resample_(pair|tiled)_kernel<",
+}
+
+
+def live_pmc(args, want):
+    """HBM bytes per launch from the PMC counters, measured NOW: two more passes of this very command
+    (short, without the CPU legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`
+    (separate passes, kernel trace only: MI355X_MICROARCH.md), FETCH_SIZE x 2 (gfx950 counts 64 B per
+    128-B request; calibrated for this library's access widths in profiles/r03_fetch_calibration.txt)
+    + WRITE_SIZE.  `want`: {label: (device kernel regex, largest_only)}.  Returns {label: bytes or None};
+    any failure (no rocprofv3, a timeout) gives None and the committed figure is used instead."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {}
+    out = tempfile.mkdtemp(prefix="pipe_bench_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc",
+             "--config", str(args.config), "--frames", str(args.frames), "--taps", str(args.taps), "--dtype", args.dtype]
+    for name in ("buffers", "channels", "lines"):
+        if getattr(args, name) is not None:
+            child += [f"--{name}", str(getattr(args, name))]
+    if args.no_secondary:
+        child.append("--no-secondary")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = ["timeout", "-k", "5", "240", "rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            per = {}
+            for p in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                db = sqlite3.connect(p)
+                for name, cname, val, disp in db.execute("select name, counter_name, counter_value, dispatch_id from pmc_events"):
+                    if cname == counter:
+                        key = (p, disp)
+                        per[key] = (name, per.get(key, (name, 0.0))[1] + val)  # one row per XCC: summed
+            for label, (pat, largest_only) in want.items():
+                vals = [v for (n, v) in per.values() if re.search(pat, n)]
+                if largest_only and vals:
+                    top = max(vals)
+                    vals = [v for v in vals if v >= 0.5 * top]
+                sums.setdefault(label, {})[counter] = (sum(vals) / len(vals)) if vals else None
+    except (OSError, subprocess.SubprocessError, sqlite3.Error):
+        sums = {}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for label, c in sums.items():
+        f, w = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
+        res[label] = int((2 * f + w) * 1024) if f and w else None
+    return res
 
 
 def free_port() -> int:
@@ -477,6 +542,27 @@ def run_rank(args, rank, world, local, sync, launch):
                              "roofline_frac": round(3 * nm * 4 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             result["c5_resampler_mix"] = c5
             del do
+
+    # roofline.traffic measured in THIS run (N = 1): the committed figure above stays only if the passes fail
+    if rank == 0 and world == 1 and not args.no_live_pmc and os.environ.get("PIPE_BENCH_LIVE_PMC", "1") != "0":
+        want = {"main": (PMC_KERNELS["main_chain" if is_fused else "main_ols"], True)} if is_ols else {}
+        if "c4_chain" in result and cfg == 1:
+            want["c4_chain"] = (PMC_KERNELS["c4_chain"], False)
+        if "c5_resampler_mix" in result:
+            want["c5_resampler"] = (PMC_KERNELS["c5_resampler"], False)
+        t_pmc = time.perf_counter()
+        live = live_pmc(args, want) if want else {}
+        src_live = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x 2 + WRITE_SIZE)"
+        src_file = "profiles/pmc_latest.json (committed; kernel, bytes and source hash match this build)"
+        result["roofline"]["traffic_source"] = src_file if result["roofline"]["traffic"] else None
+        if live.get("main"):
+            result["roofline"]["traffic"], result["roofline"]["traffic_source"] = live["main"], src_live
+        if live.get("c4_chain"):
+            result["c4_chain"]["traffic"], result["c4_chain"]["traffic_source"] = live["c4_chain"], src_live
+        if live.get("c5_resampler"):
+            result["c5_resampler_mix"]["resampler"]["traffic"] = live["c5_resampler"]
+            result["c5_resampler_mix"]["resampler"]["traffic_source"] = src_live
+        result["roofline"]["pmc_passes_s"] = round(time.perf_counter() - t_pmc, 1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # cpu_baseline leg: the oracle is the thing timed

@@ -35,7 +35,10 @@ def test_default_line_has_every_contract_field():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) < 1.0
     assert r["algorithmic_bytes_per_launch"] == 8 * 4096 * 4096 * 2     # 8 B per scalar sample
-    assert r["traffic"] is None or r["traffic"] > 0
+    # HBM traffic from the PMC counters, measured by two more passes of the command itself
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.6
+    if r["traffic"] is not None:
+        assert r["traffic_source"].startswith(("live", "profiles/"))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Msamples/s" and c["sample"]
     assert d["bit_exact_form"]["kernel"] == "fir_direct_kernel"
@@ -53,7 +56,7 @@ def test_default_line_has_every_contract_field():
 
 
 def test_config3_line_names_the_fused_chain():
-    d = run_bench("--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline")
+    d = run_bench("--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc")
     assert "configs[3]" in d["config"]["workload"] and d["scaling"] == "strong"
     assert d["roofline"]["kernel"].startswith("chain_fused_kernel") and d["config"]["lines_total"] == 512
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 512 * 4096 * 8
@@ -65,7 +68,7 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     device between the ranks over gloo: a rehearsal of the launch / barrier / reduce logic, no scaling
     figure -- run.go:112-132 Lines share nothing, merger.go:25-30 one executor per goroutine)."""
     d = run_bench("--gpus", "2", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-                  env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
+                  "--no-live-pmc", env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
     assert "self-spawned" in d["config"]["ranks"] and d["scaling"] == "strong"
     # value counts BOTH ranks' samples: 512 Lines x 4096 x 8 per step over the slowest rank's time
