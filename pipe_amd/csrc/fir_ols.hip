@@ -501,8 +501,10 @@ int Plan::init(int device, const double *taps, int ntaps)
     PH_HIP(hipMemcpy(impl_->tw2.p, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
     PH_TRY(init_ols32_tables(impl_));
     if (ntaps > 512) {
+        // partitions of exactly 512 taps (the last one zero-padded): the hop of the frequency-domain
+        // delay line; PIPE_HIP_FIR_PARTITION_SUM cuts them evenly for the sum-of-partitions kernel (A/B)
         impl_->P = (ntaps + 511) / 512;
-        impl_->Np = (ntaps + impl_->P - 1) / impl_->P;
+        impl_->Np = std::getenv("PIPE_HIP_FIR_PARTITION_SUM") ? (ntaps + impl_->P - 1) / impl_->P : 512;
         const size_t pb = sizeof(double) * 2 * (kHalf + 1) * (size_t)impl_->P;
         PH_TRY(impl_->hpart[0].alloc(pb));
         PH_TRY(impl_->hpart[1].alloc(pb));

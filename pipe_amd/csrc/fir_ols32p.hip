@@ -2,18 +2,24 @@
 //
 // The taps are cut into P partitions of Np <= 512 taps, h = sum_p h_p delayed by p Np frames, so
 //     y[n] = sum_p (h_p * x)[n - p Np].
-// For an output tile of L = 1025 - Np frames, partition p's contribution is the circular convolution of
-// h_p with the 1024-frame window that starts p Np frames EARLIER than partition 0's -- and the valid
-// outputs of every partition sit at the SAME window indices (i >= Np - 1).  Their spectra therefore
-// add: one forward transform per partition, Y = sum_p X_p H_p, ONE inverse transform per tile --
-// P + 1 transforms per L outputs instead of the 2 P of P full passes, and no float64 intermediate
-// through HBM.  A transform needs all 128 of a lane's data registers, so the tile's running sum
-// cannot stay in registers while the next partition's window is transformed: it waits in a per-wave
-// scratch area ([register][lane], so that the accesses coalesce; 32 KB per wave, L2 / Infinity-Cache
-// resident: written once and read once per partition after the first).
+// For an output tile, partition p's contribution is the circular convolution of h_p with the 1024-frame
+// window that starts p Np frames EARLIER than partition 0's -- and the valid outputs of every partition
+// sit at the SAME window indices.  Their spectra therefore add: Y = sum_p X_p H_p, ONE inverse
+// transform per tile, no float64 intermediate through HBM.  Two kernels:
 //
-// Same contract as the one-spectrum form: float64 arithmetic, the float32 result within one ulp of
-// the oracle's ordered sum at the filter's full scale (tests/test_gpu_fir_ols.py).
+//   fir_ols32d_kernel (shipped): hop = partition = 512 frames.  Partition p's window of tile t is then
+//     partition 0's window of tile t - p, so a half-wave that runs consecutive tiles of one series needs
+//     ONE forward transform per tile and reads the other P - 1 spectra from a ring it wrote itself:
+//     two transforms per tile for any P.
+//   fir_ols32p_kernel (PIPE_HIP_FIR_PARTITION_SUM, A/B): partitions of ceil(N / P) taps, tiles of
+//     1025 - Np outputs dealt like the one-spectrum kernel's, P forward transforms per tile, the running
+//     sum parked in a per-wave scratch area between them (a transform needs all 128 of a lane's data
+//     registers).
+//
+// Ring and scratch are device memory, [slot][register][lane] so that the accesses coalesce: L2 /
+// Infinity-Cache traffic.  Same contract as the one-spectrum form: float64 arithmetic, the float32
+// result within one ulp of the oracle's ordered sum at the filter's full scale
+// (tests/test_gpu_fir_ols.py).
 #include <cstdlib>
 #include <vector>
 
@@ -224,6 +230,217 @@ fir_ols32p_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
     }
 }
 
+// ---- frequency-domain delay line: two transforms per tile for ANY number of partitions ---------------
+// With hop = partition = 512 frames (taps zero-padded to P x 512) partition p's window of tile t IS
+// partition 0's window of tile t - p: X_{t,p} = X_{t-p}.  A half-wave that runs R consecutive tiles of
+// one series therefore needs ONE forward transform per tile, keeps the last P spectra in a ring
+// ([slot][register][lane] in device memory, L2 / Infinity-Cache traffic) and forms
+//     Y_t = sum_p X_{t-p} H_p                       then ONE inverse transform.
+// A run starts with P - 1 forward transforms of the windows before its first tile (history / earlier
+// input), so runs are long compared with P (the host picks R).  Both halves of a wave run consecutive
+// runs of the same series: one buffer resource serves both windows.
+struct ArgsD {
+    Args32 a;             // HP = L = 512; tiles_per_line = ceil(frames / 512); H = N - 1 (the whole history)
+    int P, R;             // partitions; tiles per run (a multiple of P)
+    int upl;              // units (pairs of runs) per (Line, pair) series
+    int64_t nunits;
+    const double2 *hpart; // [P][kHalf32 + 1]
+    double2 *ring;        // [waves][P][32 registers][64 lanes]
+};
+
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(kWaves32 * 64)
+fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
+                  const double2 *__restrict__ tw_g, const ArgsD t)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2 *tws = reinterpret_cast<double2 *>(smem_raw);
+    double *planes = reinterpret_cast<double *>(tws + 31 * 32);
+    const Args32 &a = t.a;
+
+    fir_history_carry(in_base, hist_base, static_cast<double *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
+    for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
+        tws[i] = tw_g[32 + i];
+    __syncthreads();
+
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane_ = threadIdx.x & 63;
+    const int l5_ = lane_ & 31;
+    using In2 = typename Pair<TIn>::type;
+    const int nb = (int)gridDim.x;
+    const int64_t wave_global = (int64_t)wave_u * nb + (int)blockIdx.x;
+    const int64_t wave_stride = (int64_t)nb * kWaves32;
+    double2 *wave_ring = t.ring + ((int64_t)blockIdx.x * kWaves32 + wave_u) * (int64_t)t.P * (32 * 64);
+    const unsigned in_step = (unsigned)(32 * a.C * sizeof(TIn));
+    const unsigned out_step = (unsigned)(32 * a.C * sizeof(TOut));
+    // (a step past the end of the Line bases its resources beyond the Line: zero records, so that the
+    // out-of-range offset of its lanes IS out of range)
+    auto bytes31 = [](int64_t n) { return (int)(n < 0 ? 0 : (n < 0x7FFFFFFF ? n : 0x7FFFFFFF)); };
+    const int64_t last = a.frames - 1;
+    constexpr int kL = 512;  // hop = partition = window overlap
+
+    for (int64_t unit = wave_global; unit < t.nunits; unit += wave_stride) {
+        // unit -> (series, pair of runs): half h runs tiles [tb, te) of series (line, pair)
+        const int series = __builtin_amdgcn_readfirstlane((int)(unit / t.upl));
+        const int uidx = __builtin_amdgcn_readfirstlane((int)(unit - (int64_t)series * t.upl));
+        const int line = series / a.pairs, c0 = 2 * (series - line * a.pairs);
+        const int tb0 = 2 * uidx * t.R;                         // half 0's first tile
+        cd lo[16], hi[16];
+        // one step: WARM = a window before the run's first tile (its spectrum is all it is for)
+        auto step = [&](int rel, auto warm_c) {
+            constexpr bool WARM = decltype(warm_c)::value;
+            // (per-lane quantities from opaque copies of the lane indices: nothing invariant over the
+            // tiles is kept in registers through the transforms)
+            int l5 = l5_, lane = lane_;
+            asm volatile("" : "+v"(l5), "+v"(lane));
+            const int half = lane >> 5;
+            double *plane = planes + (wave_u * 2 + half) * kPlane32;
+            double *pa = plane + l5;
+            double *pb = plane + 33 * l5;
+            const double2 *__restrict__ twl = tws + l5 - 32;
+            const int tile0 = tb0 + rel;                        // half 0's tile of this step (warm-up: may be < 0)
+            const int tile = tile0 + half * t.R;
+            // a half whose run lies past the series' last tile does nothing; a warm-up step of a run
+            // only transforms; a step past the end of a (shorter, last) run does nothing either
+            const bool run_exists = tb0 + half * t.R < a.tiles_per_line;
+            const bool out_step_ok = rel >= 0 && tile < a.tiles_per_line;
+            const bool valid = run_exists && (rel < 0 || tile < a.tiles_per_line);
+            const int cur = ((tile0 % t.P) + t.P) % t.P;        // ring slot of this step's spectrum (R % P == 0: the same for both halves)
+
+            // ---- the window of tile `tile`: frames [tile * 512 - 512, tile * 512 + 512) ----------------
+            const int64_t fr00 = (int64_t)tile0 * kL - kL;
+            if (fr00 >= 0) {
+                const TIn *base = in_base + (int64_t)line * a.line_stride + fr00 * a.C;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(base), 0, bytes31((a.frames - fr00) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+                unsigned v0 = valid ? (unsigned)(((half * t.R * kL + l5) * a.C + c0) * (int)sizeof(TIn)) : kOut32;
+                asm volatile("" : "+v"(v0));
+                In2 pf[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
+            } else {
+                const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
+                const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
+                const int64_t fr0 = (int64_t)tile * kL - kL;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int64_t g = fr0 + l5 + 32 * r;
+                    double re = 0.0, im = 0.0;
+                    if (valid) {
+                        if (g >= 0) {
+                            if (g <= last) {
+                                re = (double)in[g * a.C + c0];
+                                im = (double)in[g * a.C + c0 + 1];
+                            }
+                        } else if (g >= -(int64_t)a.H) {  // (older frames meet zero-padded taps only)
+                            re = hist[(g + a.H) * a.C + c0];
+                            im = hist[(g + a.H) * a.C + c0 + 1];
+                        }
+                    }
+                    PH_NAT(r) = cd{re, im};
+                }
+            }
+            ols32_forward(lo, hi, pa, pb, twl);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- into the ring; for a tile of the run: Y = sum_p X_{t-p} H_p ----------------------------
+            double2 *__restrict__ slot_cur = wave_ring + (int64_t)cur * (32 * 64) + lane;
+            const double2 *__restrict__ hp0 = t.hpart;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                double2 h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k1 = 4 * g + i;
+                    h[i] = k1 < 16 ? hp0[32 * k1 + l5] : hp0[1024 - 32 * k1 - l5];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k1 = 4 * g + i;
+                    slot_cur[k1 * 64] = double2{PH_SPL(k1).re, PH_SPL(k1).im};
+                    if constexpr (!WARM) {
+                        const cd w{h[i].x, k1 < 16 ? h[i].y : -h[i].y};
+                        PH_SPL(k1) = cmul(PH_SPL(k1), w);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (WARM)
+                return;
+#pragma unroll 1
+            for (int p = 1; p < t.P; ++p) {
+                int l5p = l5, lanep = lane;
+                asm volatile("" : "+v"(l5p), "+v"(lanep));
+                const int sp = cur - p < 0 ? cur - p + t.P : cur - p;
+                const double2 *__restrict__ xs = wave_ring + (int64_t)sp * (32 * 64) + lanep;
+                const double2 *__restrict__ hp = t.hpart + (size_t)p * (kHalf32 + 1);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    double2 h[4], x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k1 = 4 * g + i;
+                        h[i] = k1 < 16 ? hp[32 * k1 + l5p] : hp[1024 - 32 * k1 - l5p];
+                        x[i] = xs[k1 * 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k1 = 4 * g + i;
+                        const cd w{h[i].x, k1 < 16 ? h[i].y : -h[i].y};
+                        const cd v = cmul(cd{x[i].x, x[i].y}, w);
+                        PH_SPL(k1).re += v.re;
+                        PH_SPL(k1).im += v.im;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ols32_inverse_plain(lo, hi, pa, pb, twl);
+            // ---- store: window index i >= 512 is frame tile * 512 + i - 512 -----------------------------
+            {
+                const int64_t t00 = (int64_t)tile0 * kL;
+                TOut *base = out_base + (int64_t)line * a.line_stride + t00 * a.C;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    base, 0, bytes31((a.frames - t00) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
+                const int o0 = ((half * t.R * kL + l5 - kL) * a.C + c0) * (int)sizeof(TOut);
+                const int i0 = out_step_ok ? l5 - kL : -2048;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int off = o0 + r * (int)out_step;
+                    buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+                }
+            }
+        };
+#pragma unroll 1
+        for (int rel = 1 - t.P; rel < 0; ++rel)
+            step(rel, std::true_type{});
+#pragma unroll 1
+        for (int rel = 0; rel < t.R; ++rel)
+            step(rel, std::false_type{});
+    }
+}
+
+template <typename TIn, typename TOut>
+int launch32d(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, ArgsD t, hipStream_t s,
+              KernelTimer *timer)
+{
+    auto kfn = fir_ols32d_kernel<TIn, TOut>;
+    const size_t lds = sizeof(double2) * (31 * 32) + sizeof(double) * (size_t)kPlane32 * 2 * kWaves32;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    const int64_t wanted = (t.nunits + kWaves32 - 1) / kWaves32;
+    const unsigned grid = (unsigned)(wanted < I.cus ? wanted : I.cus);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (timer)
+        PH_TRY(timer->pair(&ev_a, &ev_b));
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
+                          static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw32.p), t);
+    PH_HIP(hipGetLastError());
+    return PIPE_HIP_OK;
+}
+
 template <typename TIn, typename TOut>
 int launch32p(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, ArgsP t, hipStream_t s,
               KernelTimer *timer)
@@ -253,6 +470,54 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
                double *hist_new, int64_t frames, int channels, int lines, hipStream_t s, const char **kernel_name,
                KernelTimer *timer)
 {
+    // the frequency-domain delay line (two transforms per tile): the plan's spectra are cut every 512
+    // taps for it (Plan::init); PIPE_HIP_FIR_PARTITION_SUM selects the sum-of-partitions kernel (A/B)
+    if (I.Np == 512 && !std::getenv("PIPE_HIP_FIR_PARTITION_SUM")) {
+        ArgsD d{};
+        Args32 &a = d.a;
+        a.frames = frames;
+        a.hist_new = hist_new;
+        a.line_stride = frames * channels;
+        a.C = channels;
+        a.N = I.N;
+        a.H = I.N - 1;
+        a.HP = 512;
+        a.L = 512;
+        a.pairs = channels / 2;
+        a.lines = lines;
+        a.tiles_per_line = (int)((frames + 511) / 512);
+        d.P = I.P;
+        const int64_t series = (int64_t)lines * a.pairs;
+        const int64_t waves = (int64_t)kWaves32 * I.cus;
+        // tiles per run: enough runs for every half-wave, long enough to amortise the P - 1 warm-up
+        // transforms, a multiple of P (both halves of a wave then use the same ring slot)
+        int64_t R = ((int64_t)a.tiles_per_line * series + 2 * waves - 1) / (2 * waves);
+        if (R < 4 * (int64_t)d.P)
+            R = 4 * (int64_t)d.P;
+        R = (R + d.P - 1) / d.P * d.P;
+        d.R = (int)R;
+        d.upl = (int)((a.tiles_per_line + 2 * R - 1) / (2 * R));
+        d.nunits = (int64_t)d.upl * series;
+        d.hpart = static_cast<const double2 *>(I.hpart[I.cur].p);
+        const size_t need = sizeof(double2) * 32 * 64 * (size_t)kWaves32 * (size_t)I.cus * (size_t)d.P;
+        if (I.scratch.bytes < need)
+            PH_TRY(I.scratch.alloc(need));
+        d.ring = static_cast<double2 *>(I.scratch.p);
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+            *kernel_name = "fir_ols_kernel<f32,f32,32x32,partitioned>";
+            return launch32d<float, float>(I, d_in, d_out, hist, d, s, timer);
+        }
+        if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
+            *kernel_name = "fir_ols_kernel<f64,f32,32x32,partitioned>";
+            return launch32d<double, float>(I, d_in, d_out, hist, d, s, timer);
+        }
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
+            *kernel_name = "fir_ols_kernel<f32,f64,32x32,partitioned>";
+            return launch32d<float, double>(I, d_in, d_out, hist, d, s, timer);
+        }
+        *kernel_name = "fir_ols_kernel<f64,f64,32x32,partitioned>";
+        return launch32d<double, double>(I, d_in, d_out, hist, d, s, timer);
+    }
     ArgsP t{};
     Args32 &a = t.a;
     a.frames = frames;

@@ -59,11 +59,16 @@ def run_batch(taps, x, F, K, lines, exact):
 
 @pytest.mark.parametrize("channels,ntaps,F,K", [(2, 1024, 1024, 24), (2, 513, 1024, 24), (4, 700, 512, 40), (2, 4096, 4096, 8),
                                                  (8, 1500, 2048, 6), (2, 2049, 300, 70)])
-def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, monkeypatch):
+@pytest.mark.parametrize("form", ["delay_line", "partition_sum"])
+def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, form, monkeypatch):
     """513 .. 4096 taps: several <= 512-tap spectra whose products are summed in the frequency domain
-    (fir_ols32p.hip).  Same contract as the one-spectrum form; two launches, so the N - 1 frames of
-    history (deeper than a tile) carry across; the direct form on the same data stays bit-exact."""
+    (fir_ols32p.hip) -- as a frequency-domain delay line (one forward transform per 512-frame tile, the
+    last P spectra in a ring: the shipped form) and as a sum over the partitions' own windows (A/B form).
+    Same contract as the one-spectrum form; two launches, so the N - 1 frames of history (deeper than a
+    tile) carry across; the direct form on the same data stays bit-exact."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    if form == "partition_sum":
+        monkeypatch.setenv("PIPE_HIP_FIR_PARTITION_SUM", "1")
     lines = 2
     taps = synth.fir_lowpass_taps(ntaps, fc=0.11, f32_rounded=True)
     x = np.stack([synth.samples(synth.line_seed(80 + l), 0, K * F * channels, np.float32).reshape(K * F, channels)
@@ -295,3 +300,33 @@ def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
         want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(frames, channels)
         assert np.array_equal(ref[l], want.astype(np.float32)), f"direct form, line {l}"
         assert ulp_diff_f32(got[l], want, floor).max() <= 1.0, f"overlap-save form, line {l}"
+
+
+def test_partitioned_delay_line_many_short_lines_three_calls(monkeypatch):
+    """The delay line's runs on many short Lines (a run longer than a Line's tiles, halves without a
+    run, Lines ending inside a tile) over three calls of different lengths: every Line against the oracle."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, ntaps, F = 37, 4, 1100, 700
+    taps = synth.fir_lowpass_taps(ntaps, fc=0.07, f32_rounded=True)
+    calls = [3 * F, F, 5 * F - 13]
+    total = sum(calls)
+    x = np.stack([synth.samples(synth.line_seed(300 + l), 0, total * C, np.float32).reshape(total, C) for l in range(lines)])
+    with P.Fir(taps, F, C, dtype=np.float32, lines=lines, max_batch=8) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        outs, pos = [], 0
+        for n in calls:
+            xin = d_in[:, pos:pos + n, :].contiguous()
+            y = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, y, n)
+            torch.cuda.synchronize()
+            assert "partitioned" in p.kernel_name()
+            outs.append(y)
+            pos += n
+        got = torch.cat(outs, dim=1).cpu().numpy()
+    assert not np.isnan(got).any()
+    floor = 2.0 ** -24 * np.abs(taps).sum()
+    for l in range(lines):
+        want = O.Fir(taps, C).process(x[l].astype(np.float64)).reshape(total, C)
+        d = ulp_diff_f32(got[l], want, floor)
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at {np.unravel_index(d.argmax(), d.shape)}"
