@@ -141,7 +141,9 @@ def live_pmc(args, want):
     (short, without the CPU legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`
     (separate passes, kernel trace only: MI355X_MICROARCH.md), FETCH_SIZE x 2 (gfx950 counts 64 B per
     128-B request; calibrated for this library's access widths in profiles/r03_fetch_calibration.txt)
-    + WRITE_SIZE.  `want`: {label: (device kernel regex, largest_only)}.  Returns {label: bytes or None};
+    + WRITE_SIZE.  `want`: {label: (device kernel regex, algorithmic bytes per launch)}: the same device
+    kernel may run several of this file's workloads (the headline and c3_shape), so only the dispatches
+    whose counter is within 2.5x of what the algorithmic bytes predict are averaged.  Returns {label: bytes or None};
     any failure (no rocprofv3, a timeout) gives None and the committed figure is used instead."""
     import re
     import shutil
@@ -173,11 +175,10 @@ def live_pmc(args, want):
                     if cname == counter:
                         key = (p, disp)
                         per[key] = (name, per.get(key, (name, 0.0))[1] + val)  # one row per XCC: summed
-            for label, (pat, largest_only) in want.items():
-                vals = [v for (n, v) in per.values() if re.search(pat, n)]
-                if largest_only and vals:
-                    top = max(vals)
-                    vals = [v for v in vals if v >= 0.5 * top]
+            for label, (pat, alg) in want.items():
+                # bytes in ~ bytes out ~ alg / 2; FETCH_SIZE (KiB) counts half of the bytes read
+                expect_kib = alg / (4.0 if counter == "FETCH_SIZE" else 2.0) / 1024.0
+                vals = [v for (n, v) in per.values() if re.search(pat, n) and 0.4 < v / expect_kib < 2.5]
                 sums.setdefault(label, {})[counter] = (sum(vals) / len(vals)) if vals else None
     except (OSError, subprocess.SubprocessError, sqlite3.Error):
         sums = {}
@@ -545,11 +546,11 @@ def run_rank(args, rank, world, local, sync, launch):
 
     # roofline.traffic measured in THIS run (N = 1): the committed figure above stays only if the passes fail
     if rank == 0 and world == 1 and not args.no_live_pmc and os.environ.get("PIPE_BENCH_LIVE_PMC", "1") != "0":
-        want = {"main": (PMC_KERNELS["main_chain" if is_fused else "main_ols"], True)} if is_ols else {}
+        want = {"main": (PMC_KERNELS["main_chain" if is_fused else "main_ols"], alg_bytes)} if is_ols else {}
         if "c4_chain" in result and cfg == 1:
-            want["c4_chain"] = (PMC_KERNELS["c4_chain"], False)
+            want["c4_chain"] = (PMC_KERNELS["c4_chain"], result["c4_chain"]["algorithmic_bytes_per_launch"])
         if "c5_resampler_mix" in result:
-            want["c5_resampler"] = (PMC_KERNELS["c5_resampler"], False)
+            want["c5_resampler"] = (PMC_KERNELS["c5_resampler"], result["c5_resampler_mix"]["resampler"]["algorithmic_bytes_per_launch"])
         t_pmc = time.perf_counter()
         live = live_pmc(args, want) if want else {}
         src_live = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x 2 + WRITE_SIZE)"

@@ -111,8 +111,8 @@ int pipe_hip_resampler_create(const pipe_hip_config *cfg, const double *proto,
  * merges error channels, not signals: SURVEY.md F2.) */
 int pipe_hip_mix_create(const pipe_hip_config *cfg, int32_t inputs, pipe_hip_processor **out);
 /* A Line's Processors slice (line.go:17) run back to back on the device with
- * float64 intermediates that never leave HBM/LDS -- or, for FIR -> biquad (one section) [-> gain]
- * on large float32 batches, as ONE kernel with no intermediates at all (see PIPE_HIP_PARAM_EXACT
+ * float64 intermediates that never leave HBM/LDS -- or, for FIR -> biquad (one or two sections)
+ * [-> gain] on large float32 batches, as ONE kernel with no intermediates at all (see PIPE_HIP_PARAM_EXACT
  * for its bound).  Takes ownership of the stages (destroying the chain destroys them).  All stages
  * must share cfg. */
 int pipe_hip_chain_create(pipe_hip_processor *const *stages, int32_t n_stages,

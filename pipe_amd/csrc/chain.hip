@@ -60,11 +60,11 @@ public:
                 bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
                 const int64_t L = 1024 - (fv.ntaps - 1 + 31) / 32 * 32;
                 const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
-                if (items >= fv.min_items) {
+                if (!fused_)
+                    fused_.reset(new fused::Plan());
+                if (items >= fv.min_items && fused_->accepts(bv.coeffs, bv.sections, fv.ntaps, frames, s)) {
                     if (!stages[0]->fuse_view_fir(&fv, s, true))  // (history into the fused kernel's layout)
                         return PIPE_HIP_EHIP;
-                    if (!fused_)
-                        fused_.reset(new fused::Plan());
                     PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, frames, cfg.channels, cfg.lines, s, &timer,
                                        &last_kernel));
                     return stages[0]->fuse_commit_fir(s);

@@ -241,6 +241,7 @@ struct Plan::Impl {
     bool has_gain = false;
     double gain = 1.0;
     FuseConst<1> c1{};
+    FuseConst<2> c2{};
     int D = 1 << 30;
     unsigned epoch = 0;
     size_t rec_granules = 0;
@@ -260,7 +261,8 @@ bool Plan::enabled()
     return on;
 }
 
-// (re)build everything that depends on the coefficients or the tap count
+// (re)build everything that depends on the coefficients or the tap count.  Every section gets its own
+// table of 2 x 2 matrices (the kernel runs the sections one after the other, ols32_kernel.hpp).
 int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
 {
     Impl &I = *impl_;
@@ -268,30 +270,13 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     if (I.S == S && I.H == H && I.coeffs.size() == (size_t)5 * S &&
         std::memcmp(I.coeffs.data(), coeffs, sizeof(double) * 5 * S) == 0)
         return PIPE_HIP_OK;
-    const int n = 2 * S;
-    const Mat M = one_step(coeffs, S);
-    const Mat M32 = power(M, 32);
-    const Mat ML = power(M, L);
-    std::vector<Mat> T(33);
-    T[0] = identity(n);
-    for (int j = 1; j <= 32; ++j)
-        T[j] = mul(T[j - 1], ML);
+    if (S < 1 || S > kMaxFusedSections)
+        return PIPE_HIP_EINVAL;
     constexpr int kNever = 1 << 30;  // the filter does not forget within a look-back window
-    int D = kNever;
-    for (int j = 1; j <= 32 && D == kNever; ++j) {
-        ld big = 0;
-        for (int i = 0; i < n; ++i)
-            for (int k = 0; k < n; ++k)
-                big = std::fmax(big, std::fabs(T[j].m[i][k]));
-        if (big < 0x1p-60L)
-            D = j;
-    }
-    I.D = D;
-    std::memcpy(I.c1.c, coeffs, sizeof(double) * 5 * (S < 1 ? S : 1));
-    I.c1.D = D;
     // the matrices are double-buffered on the device and staged through pinned memory: a
     // coefficient mutation uploads them on the launch stream, nothing waits for the device
-    const size_t bytes = sizeof(double) * ols::kMatCount * kMaxN2 * kMaxN2;
+    const size_t mm = 4, per_section = (size_t)ols::kMatCount * mm;
+    const size_t bytes = sizeof(double) * per_section * kMaxFusedSections;
     if (!I.mats[0].p) {
         PH_TRY(I.mats[0].alloc(bytes));
         PH_TRY(I.mats[1].alloc(bytes));
@@ -303,46 +288,84 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     }
     void *host = nullptr;
     PH_TRY(I.upload.stage(bytes, &host));
-    double *h = static_cast<double *>(host);
-    const size_t mm = (size_t)n * n;
-    Mat ak = identity(n);
-    for (int j = 0; j <= 16; ++j) {
-        store_flat(h + (ols::kMatAk + j) * mm, ak);
-        ak = mul(ak, M32);
-    }
-    store_flat(h + ols::kMatML * mm, ML);
-    store_flat(h + ols::kMatT32 * mm, T[32]);
-    for (int j = 0; j <= 32; ++j)
-        store_flat(h + (ols::kMatTj + j) * mm, T[j]);
-    const int k0 = H / 32;
-    for (int k = 0; k < 32; ++k)
-        store_flat(h + (ols::kMatPk + k) * mm, k > k0 ? power(M, 32L * (k - k0)) : identity(n));
-    {
-        Mat w = identity(n);
-        for (int k = 0; k <= 32; ++k) {
-            store_flat(h + (ols::kMatWw + k) * mm, w);
-            w = mul(w, T[32]);
+    int Dmax = 1;
+    for (int sec = 0; sec < S; ++sec) {
+        const double *c = coeffs + 5 * sec;
+        double *h = static_cast<double *>(host) + per_section * sec;
+        const Mat M = one_step(c, 1);
+        const Mat M32 = power(M, 32);
+        const Mat ML = power(M, L);
+        std::vector<Mat> T(33);
+        T[0] = identity(2);
+        for (int j = 1; j <= 32; ++j)
+            T[j] = mul(T[j - 1], ML);
+        int D = kNever;
+        for (int j = 1; j <= 32 && D == kNever; ++j) {
+            ld big = 0;
+            for (int i = 0; i < 2; ++i)
+                for (int k = 0; k < 2; ++k)
+                    big = std::fmax(big, std::fabs(T[j].m[i][k]));
+            if (big < 0x1p-60L)
+                D = j;
+        }
+        Dmax = D > Dmax ? D : Dmax;
+        Mat ak = identity(2);
+        for (int j = 0; j <= 16; ++j) {
+            store_flat(h + (ols::kMatAk + j) * mm, ak);
+            ak = mul(ak, M32);
+        }
+        store_flat(h + ols::kMatML * mm, ML);
+        store_flat(h + ols::kMatT32 * mm, T[32]);
+        for (int j = 0; j <= 32; ++j)
+            store_flat(h + (ols::kMatTj + j) * mm, T[j]);
+        const int k0 = H / 32;
+        for (int k = 0; k < 32; ++k)
+            store_flat(h + (ols::kMatPk + k) * mm, k > k0 ? power(M, 32L * (k - k0)) : identity(2));
+        {
+            Mat w = identity(2);
+            for (int k = 0; k <= 32; ++k) {
+                store_flat(h + (ols::kMatWw + k) * mm, w);
+                w = mul(w, T[32]);
+            }
+        }
+        {
+            // g_i = M^(31 - i) c, c = (b1 - a1 b0, b2 - a2 b0): sample i of a segment in its zero-start end state
+            const ld b0 = c[0], b1 = c[1], b2 = c[2], a1 = c[3], a2 = c[4];
+            ld g[2] = {b1 - a1 * b0, b2 - a2 * b0};
+            double *gz = h + ols::kMatGz * mm;
+            for (int i = 31; i >= 0; --i) {
+                gz[2 * i] = (double)g[0];
+                gz[2 * i + 1] = (double)g[1];
+                const ld t0 = M.m[0][0] * g[0] + M.m[0][1] * g[1], t1 = M.m[1][0] * g[0] + M.m[1][1] * g[1];
+                g[0] = t0;
+                g[1] = t1;
+            }
         }
     }
-    if (S == 1) {
-        // g_i = M^(31 - i) c, c = (b1 - a1 b0, b2 - a2 b0): sample i of a segment in its zero-start end state
-        const ld b0 = coeffs[0], b1 = coeffs[1], b2 = coeffs[2], a1 = coeffs[3], a2 = coeffs[4];
-        ld g[2] = {b1 - a1 * b0, b2 - a2 * b0};
-        double *gz = h + ols::kMatGz * mm;
-        for (int i = 31; i >= 0; --i) {
-            gz[2 * i] = (double)g[0];
-            gz[2 * i + 1] = (double)g[1];
-            const ld t0 = M.m[0][0] * g[0] + M.m[0][1] * g[1], t1 = M.m[1][0] * g[0] + M.m[1][1] * g[1];
-            g[0] = t0;
-            g[1] = t1;
-        }
-    }
+    I.D = Dmax;  // (the slowest section decides)
+    std::memcpy(I.c1.c, coeffs, sizeof(double) * 5);
+    std::memcpy(I.c2.c, coeffs, sizeof(double) * 5 * (S < 2 ? 1 : 2));
+    I.c1.D = I.c2.D = Dmax;
     I.cur_mats ^= 1;
-    PH_TRY(I.upload.commit(I.mats[I.cur_mats].p, sizeof(double) * ols::kMatCount * mm, s));
+    PH_TRY(I.upload.commit(I.mats[I.cur_mats].p, bytes, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);
     I.S = S;
     I.H = H;
     return PIPE_HIP_OK;
+}
+
+// Can this cascade run fused on a call of `frames` frames?  One section: always (slow filters take the
+// general look-back, a ragged end the tail kernel).  Two sections: forgetful filters and Lines that end
+// on a segment boundary only.
+bool Plan::accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipStream_t s)
+{
+    if (S == 1)
+        return true;
+    if (S != 2 || frames % 32 != 0 || std::getenv("PIPE_HIP_CHAIN_GENERAL") || std::getenv("PIPE_HIP_CHAIN_ONE_SECTION"))
+        return false;
+    if (prepare(coeffs, S, ntaps, s) != PIPE_HIP_OK)
+        return false;
+    return impl_->D <= 32;
 }
 
 // Precondition: the stream the last launch went to has been synchronised (every caller has just
@@ -365,13 +388,21 @@ int Plan::poll_error()
 // Every workgroup of a fused launch must be resident at once (tiles wait for their predecessors):
 // one 512-thread workgroup with this much LDS has to fit a CU.  Asked once per kernel form; a
 // device (or a runtime LDS carve-out) where it does not fit takes the staged chain instead.
+// tables + exchange planes + (LOCAL) one ring of records per section and the round counters
+template <int S, bool LOCAL>
+static constexpr size_t fused_lds_bytes()
+{
+    return sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) + sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
+           (LOCAL ? (S < 2 ? sizeof(ols::LocalRec<4>) * ols::kLocalRing : S * sizeof(ols::LocalRec<4>) * ols::kLocalRing2) +
+                        4 * sizeof(unsigned)
+                  : 0);
+}
+
 template <int S, bool GENERAL, bool LOCAL>
 static bool form_fits()
 {
     auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
-    const size_t lds = sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) +
-                       sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
-                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing + 4 * sizeof(unsigned) : 0);
+    const size_t lds = fused_lds_bytes<S, LOCAL>();
     int per_cu = 0;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess ||
@@ -395,7 +426,10 @@ bool Plan::launchable()
     dev &= 63;
     std::lock_guard<std::mutex> lock(mu);
     if (!known[dev])
-        known[dev] = form_fits<1, true, false>() && form_fits<1, false, true>() && form_fits<1, false, false>() ? 1 : 2;
+        known[dev] = form_fits<1, true, false>() && form_fits<1, false, true>() && form_fits<1, false, false>() &&
+                             form_fits<2, false, true>() && form_fits<2, false, false>()
+                         ? 1
+                         : 2;
     return known[dev] == 1;
 }
 
@@ -406,8 +440,12 @@ int Plan::export_state(hipStream_t s)
     Impl &I = *impl_;
     if (!I.in_slots)
         return PIPE_HIP_OK;
-    hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
-                       I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
+    if (I.S == 2)
+        hipLaunchKernelGGL(chain_state_export_kernel<2>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
+    else
+        hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
     PH_HIP(hipGetLastError());
     I.in_slots = false;
     return PIPE_HIP_OK;
@@ -420,9 +458,7 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
 {
     auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
-    const size_t lds = sizeof(double2) * (ols::kHalf32 + 1 + 31 * 32) +
-                       sizeof(double) * (size_t)ols::kPlane32 * 2 * kWaves32 +
-                       (LOCAL ? sizeof(ols::LocalRec<4 * S>) * ols::kLocalRing + 4 * sizeof(unsigned) : 0);
+    const size_t lds = fused_lds_bytes<S, LOCAL>();
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     // every workgroup of the grid must be resident (tiles wait for their predecessors): one
@@ -548,9 +584,14 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     I.bq_state = bq.state;
     if (!I.in_slots) {
         ++I.epoch;
-        hipLaunchKernelGGL(chain_state_import_kernel<1>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
-                           static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
-                           I.epoch);
+        if (S == 2)
+            hipLaunchKernelGGL(chain_state_import_kernel<2>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
+                               I.epoch);
+        else
+            hipLaunchKernelGGL(chain_state_import_kernel<1>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
+                               I.epoch);
         PH_HIP(hipGetLastError());
         I.in_slots = true;
     }
@@ -577,20 +618,32 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
     static const bool force_general = std::getenv("PIPE_HIP_CHAIN_GENERAL") != nullptr;
     const bool general = force_general || I.D > 32;
-    if (S != 1)
-        return PIPE_HIP_EINVAL;  // kMaxFusedSections
-    I.c1.gain = has_gain ? gain : 1.0;
+    if (S < 1 || S > kMaxFusedSections || (S == 2 && (general || frames % 32 != 0)))
+        return PIPE_HIP_EINVAL;  // (Plan::accepts said otherwise: the caller did not ask)
+    I.c1.gain = I.c2.gain = has_gain ? gain : 1.0;
     // Block-local look-back (ols32_kernel.hpp): at least as many Lines as CUs -- a workgroup per CU,
     // whole Lines per workgroup, balanced to within one Line -- and predecessors within the record
     // ring's reach.  PIPE_HIP_CHAIN_LOCAL=0 switches it off (tests, A/B).
     const char *local_env = std::getenv("PIPE_HIP_CHAIN_LOCAL");
     const bool local = !general && !(local_env && local_env[0] == '0') && lines >= P.cus &&
-                       (int64_t)I.D * a.pairs <= ols::kLocalReach &&
+                       (int64_t)I.D * a.pairs <= (S == 2 ? ols::kLocalReach2 : ols::kLocalReach) &&
                        (lines % P.cus == 0 || lines >= 8 * P.cus);
     a.local = local ? 1 : 0;
     {
         const char *e = std::getenv("PIPE_HIP_CHAIN_STAGGER");  // A/B knob
         a.stagger = e ? std::atoi(e) : 0;
+    }
+    if (S == 2) {
+        // two sections: the sections one after the other over the tile in segment layout (ols32_kernel.hpp)
+        I.c2.D = I.D;
+        if (local) {
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain,local>";
+            PH_TRY((launch<2, false, true>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+        } else {
+            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
+            PH_TRY((launch<2, false, false>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+        }
+        return PIPE_HIP_OK;
     }
     if (general) {
         I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 
@@ -88,6 +89,17 @@ struct FuseArgs {
     int *err;                    // set when a bounded spin gives up
     unsigned long long *prof;    // PH_FUSE_PROF builds: [waves][kFuseProfPhases]
 };
+
+template <int S, typename F, int... Is>
+__device__ __forceinline__ void for_each_section_impl(F &&f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int S, typename F>
+__device__ __forceinline__ void for_each_section(F &&f)
+{
+    for_each_section_impl<S>(static_cast<F &&>(f), std::make_integer_sequence<int, S>{});
+}
 
 template <int S>
 __device__ __forceinline__ double biquad_step(double x, double (&st)[2 * S], const FuseConst<S> &fc)
@@ -201,6 +213,11 @@ __device__ __forceinline__ void own_store(unsigned long long *dst, unsigned epoc
 // plain barrier per round would do, and costs a fifth of the kernel in waves waiting for the slowest.
 constexpr int kLocalRing = 64;
 constexpr int kLocalReach = 32;  // the host checks D * pairs against this
+// Two sections: one ring per section, 48 records each, reach 16.  A record of round r is then read in
+// rounds <= r + 1 and overwritten by item g + 48 in round r + 3, whose wave starts only when every wave is
+// through round r + 1: the same argument with one round less of reach.
+constexpr int kLocalRing2 = 48;
+constexpr int kLocalReach2 = 16;
 template <int NV>
 struct LocalRec {
     double v[NV];
@@ -667,6 +684,307 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     }
 }
 
+// ---- cascades of two (or more) sections: one pass of the machinery above PER SECTION ---------------
+// A cascade's zero-input transition is 2S x 2S; run as ONE recurrence (fused_epilogue<2>) its scan,
+// look-back and pass-5 matrices do not fit a wave's registers (200+ spilled).  But a cascade is its
+// sections one after the other: section k's output is section k + 1's input, and each section alone is
+// the 2 x 2 problem.  So the tile goes to segment layout ONCE, every section runs zero-state pass, scan,
+// look-back and the ordered recurrence over it in place (channel 0 in registers, channel 1 in the
+// plane), with its own matrices, records and state slots, and the tile goes back to natural layout
+// ONCE.  The arithmetic per section is exactly the one-section epilogue's: same contract
+// (tests/test_gpu_chain_fused.py).  Forgetful filters only (every section forgets within kLocalReach
+// tiles: all audio EQs); Lines that end on a segment boundary only (the host checks both and takes the
+// staged chain otherwise).
+//   fa.mats : [S][kMatCount] 2 x 2 matrices, section-major
+//   records : [series][tile][A | P][2 NV granules], NV = 4 S: section k's aggregate at doubles
+//             2k, 2k + 1 (channel 0) and 2S + 2k, 2S + 2k + 1 (channel 1)
+//   slots   : the same order; ring: [S][kLocalRing] LocalRec<4>
+__device__ __forceinline__ double biquad_step1(double x, double (&st)[2], const double (&c)[5])
+{
+    const double y = __builtin_fma(c[0], x, st[0]);
+    const double t = __builtin_fma(c[1], x, st[1]);
+    st[0] = __builtin_fma(-c[3], y, t);
+    const double u = c[2] * x;
+    st[1] = __builtin_fma(-c[4], y, u);
+    return y;
+}
+
+template <int S, bool LOCAL>
+__device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[16], double *pa, double *pb, const Args32 &a,
+                                                        const FuseArgs &fa, const FuseConst<S> &fc, int line, int tile, int pair,
+                                                        bool valid, int l5_in, int half, LocalRec<4> *ring_all, int gi)
+{
+    (void)half;
+    int l5 = l5_in;
+    asm volatile("" : "+v"(l5));
+    constexpr int NV = 4 * S;  // doubles per series record / slot
+    const int64_t len64 = a.frames - (int64_t)tile * a.L;
+    const int len = (int)(len64 < a.L ? len64 : a.L);
+    const bool last_tile = tile == a.tiles_per_line - 1;
+    valid = valid && len > 0;
+    const int64_t series = (int64_t)line * a.pairs + pair;
+    unsigned long long *recs = fa.rec + (series * a.tiles_per_line) * (2 * 2 * NV);
+    unsigned long long *own_base = fa.own + series * (2 * 2 * NV);
+
+    // ---- to segment layout: channel 0 in registers, channel 1 in the plane's rows ---------------------
+    double xr[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+        PH_COL(r) = PH_NAT(r).re;
+    wave_fence();
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+        xr[c] = PH_ROW(c);
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+        PH_COL(r) = PH_NAT(r).im;
+    wave_fence();
+
+    // the state slot of this launch's readers / writer: the tags decide once for all sections
+    const bool mine_first = valid && tile - 1 - l5 == -1 && l5 < fc.D;  // this lane stands for "tile -1"
+    const bool ends_here = valid && last_tile && l5 == ((a.HP + len - 1) >> 5);
+
+    for_each_section<S>([&](auto sec_c) {
+        constexpr int SEC = decltype(sec_c)::value;
+        constexpr bool LAST = SEC == S - 1;
+        int l5s = l5;
+        asm volatile("" : "+v"(l5s));  // (this section's table addresses are made here, not before the previous section)
+        const double *mats = fa.mats + (size_t)SEC * kMatCount * 4;
+        const double(&cf)[5] = fc.c[SEC];
+        double m0[2][2];
+        load_mat<1>(m0, mats, kMatAk + 1);
+
+        // ---- zero-state pass: z = sum_i g_i x_i ---------------------------------------------------------
+        double zr[2] = {0.0, 0.0}, zi[2] = {0.0, 0.0};
+        {
+            double xz[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                xz[c] = PH_ROW(c);
+            typedef const __attribute__((address_space(4))) double *const_f64;
+            const const_f64 gz = (const_f64)(mats + kMatGz * 4);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const double g0 = gz[2 * c], g1 = gz[2 * c + 1];
+                zr[0] = __builtin_fma(g0, xr[c], zr[0]);
+                zr[1] = __builtin_fma(g1, xr[c], zr[1]);
+                zi[0] = __builtin_fma(g0, xz[c], zi[0]);
+                zi[1] = __builtin_fma(g1, xz[c], zi[1]);
+            }
+        }
+        if (l5s < fa.k0)
+            zr[0] = zr[1] = zi[0] = zi[1] = 0.0;
+
+        // ---- scan over the 32 segments ---------------------------------------------------------------------
+        {
+            double mn[2][2], tr[2], ti[2];
+#define PH_SCAN_STEP(D_, NEXT_)                                  \
+    load_mat<1>(mn, mats, (NEXT_));                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                \
+    {                                                            \
+        tr[j] = dpp_f64<0x110 + (D_), 0xF>(zr[j]);               \
+        ti[j] = dpp_f64<0x110 + (D_), 0xF>(zi[j]);               \
+    }                                                            \
+    affine<1>(zr, zr, m0, tr);                                   \
+    affine<1>(zi, zi, m0, ti);                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) m0[i][j] = mn[i][j];
+            PH_SCAN_STEP(1, kMatAk + 2)
+            PH_SCAN_STEP(2, kMatAk + 4)
+            PH_SCAN_STEP(4, kMatAk + 8)
+            PH_SCAN_STEP(8, kMatAk + (l5s & 15) + 1)
+#undef PH_SCAN_STEP
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                tr[j] = dpp_f64<0x142, 0xA>(zr[j]);
+                ti[j] = dpp_f64<0x142, 0xA>(zi[j]);
+            }
+            affine<1>(zr, zr, m0, tr);
+            affine<1>(zi, zi, m0, ti);
+        }
+        double er[2], ei[2], Zr[2], Zi[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double sr1 = dpp_f64<0x111, 0xF>(zr[j]), si1 = dpp_f64<0x111, 0xF>(zi[j]);
+            const double br = dpp_f64<0x142, 0xA>(zr[j]), bi = dpp_f64<0x142, 0xA>(zi[j]);
+            er[j] = l5s == 16 ? br : sr1;
+            ei[j] = l5s == 16 ? bi : si1;
+            Zr[j] = __shfl(zr[j], 31, 32);
+            Zi[j] = __shfl(zi[j], 31, 32);
+        }
+
+        // ---- publish this section's aggregate ------------------------------------------------------------
+        LocalRec<4> *ring = ring_all + SEC * kLocalRing2;
+        if (l5s == 31 && valid && !last_tile) {
+            if constexpr (LOCAL) {
+                LocalRec<4> *r = ring + gi % kLocalRing2;
+                r->v[0] = Zr[0];
+                r->v[1] = Zr[1];
+                r->v[2] = Zi[0];
+                r->v[3] = Zi[1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&r->tag, (unsigned long long)(gi / kLocalRing2 + 1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                unsigned long long *dst = recs + (int64_t)tile * 2 * (2 * NV);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned long long br = __builtin_bit_cast(unsigned long long, Zr[j]);
+                    const unsigned long long bi = __builtin_bit_cast(unsigned long long, Zi[j]);
+                    granule_store(dst + 2 * (2 * SEC + j), fa.epoch, (unsigned)br);
+                    granule_store(dst + 2 * (2 * SEC + j) + 1, fa.epoch, (unsigned)(br >> 32));
+                    granule_store(dst + 2 * (2 * S + 2 * SEC + j), fa.epoch, (unsigned)bi);
+                    granule_store(dst + 2 * (2 * S + 2 * SEC + j) + 1, fa.epoch, (unsigned)(bi >> 32));
+                }
+            }
+        }
+
+        // ---- the tile's true start state for this section: s = sum_{j < D} (M^L)^j A_{t-1-j} -----------------
+        double tj0[2][2];
+        load_mat<1>(tj0, mats, kMatTj + l5s);
+        double wr[2] = {0.0, 0.0}, wi[2] = {0.0, 0.0};
+        if (mine_first) {  // the cascade's state of the previous launch: this section's part of the newer slot
+            const unsigned long long *r = own_base + own_newer_slot<NV>(own_base, fa.epoch) * (2 * NV);
+            double pay[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = (j < 2 ? 2 * SEC + j : 2 * S + 2 * SEC + (j - 2));
+                const unsigned long long g0 = granule_load(r + 2 * d), g1 = granule_load(r + 2 * d + 1);
+                pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
+            }
+            wr[0] = pay[0];
+            wr[1] = pay[1];
+            wi[0] = pay[2];
+            wi[1] = pay[3];
+        }
+        {
+            const int u = tile - 1 - l5s;
+            const bool need = valid && l5s < fc.D && u >= -1;
+            bool ready = !(need && u >= 0);
+            unsigned spins = 0;
+            if constexpr (LOCAL) {
+                const int gp0 = gi - (l5s + 1) * a.pairs;
+                const int gp = gp0 < 0 ? 0 : gp0;  // (lanes without a predecessor do not look)
+                const LocalRec<4> *r = ring + gp % kLocalRing2;
+                const unsigned long long want = (unsigned long long)(gp / kLocalRing2 + 1);
+                while (!__all(ready)) {
+                    if (!ready) {
+                        if (__hip_atomic_load(&r->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            wr[0] = r->v[0];
+                            wr[1] = r->v[1];
+                            wi[0] = r->v[2];
+                            wi[1] = r->v[3];
+                            ready = true;
+                        } else {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 24)) {
+                                *fa.err = 1;
+                                ready = true;
+                            }
+                        }
+                    }
+                }
+            } else {
+                while (!__all(ready)) {
+                    if (!ready) {
+                        const unsigned long long *r = recs + (int64_t)u * 2 * (2 * NV);
+                        double pay[4];
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int d = (j < 2 ? 2 * SEC + j : 2 * S + 2 * SEC + (j - 2));
+                            const unsigned long long g0 = granule_load(r + 2 * d), g1 = granule_load(r + 2 * d + 1);
+                            ok = ok && (unsigned)(g0 >> 32) == fa.epoch && (unsigned)(g1 >> 32) == fa.epoch;
+                            pay[j] = __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xFFFFFFFFull));
+                        }
+                        if (ok) {
+                            wr[0] = pay[0];
+                            wr[1] = pay[1];
+                            wi[0] = pay[2];
+                            wi[1] = pay[3];
+                            ready = true;
+                        } else {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 22)) {
+                                *fa.err = 1;
+                                ready = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        double sr[2] = {0.0, 0.0}, si[2] = {0.0, 0.0};
+        {
+            double zero[2] = {0.0, 0.0}, vr[2], vi[2];
+            affine<1>(vr, zero, tj0, wr);
+            affine<1>(vi, zero, tj0, wi);
+            const int nd = fc.D < 32 ? fc.D : 32;
+            for (int d = 0; d < nd; ++d) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    sr[j] += __shfl(vr[j], d, 32);
+                    si[j] += __shfl(vi[j], d, 32);
+                }
+            }
+        }
+
+        // ---- the ordered recurrence from the true start states, in place ----------------------------------
+        double str[2], sti[2];
+        {
+            double pk[2][2];
+            load_mat<1>(pk, mats, kMatPk + l5s);
+            affine<1>(str, er, pk, sr);
+            affine<1>(sti, ei, pk, si);
+        }
+        {
+            double xi[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                xi[c] = PH_ROW(c);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                if constexpr (LAST) {
+                    xr[c] = biquad_step1(xr[c], str, cf) * fc.gain;
+                    xi[c] = biquad_step1(xi[c], sti, cf) * fc.gain;
+                } else {
+                    xr[c] = biquad_step1(xr[c], str, cf);
+                    xi[c] = biquad_step1(xi[c], sti, cf);
+                }
+            }
+            if (ends_here) {  // (the host launches this form only for Lines that end on a segment boundary)
+                unsigned long long *dst = own_write_slot<NV>(own_base, fa.epoch);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    own_store(dst + 2 * (2 * SEC + j), fa.epoch, str[j]);
+                    own_store(dst + 2 * (2 * S + 2 * SEC + j), fa.epoch, sti[j]);
+                }
+            }
+            // channel 1 back into the plane's rows: the next section's input, or on its way out
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                PH_ROW(c) = xi[c];
+            wave_fence();
+        }
+    });
+
+    // ---- back to natural layout ------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+        PH_NAT(r).im = PH_COL(r);
+    wave_fence();
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+        PH_ROW(c) = xr[c];
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+        PH_NAT(r).re = PH_COL(r);
+    wave_fence();
+}
+
 // element type of the FIR history a kernel reads and writes
 template <typename TIn, int S>
 struct HistOf {
@@ -687,14 +1005,21 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                  const FuseArgs fa, const FuseConst<(S > 0 ? S : 1)> fc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double2 *hspec = reinterpret_cast<double2 *>(smem_raw);       // H[0..512] (+ pad)
-    double2 *tws = hspec + kHalf32 + 1;                              // W1024^(k n), k = 1..31, n = 0..31
+    // (S >= 2: one ring of kLocalRing2 records per section -- the LDS has 2000 bytes to spare, two rings of
+    // 64 need 2560 more.  The tap spectrum read from global memory instead would free 8 KB, and costs the
+    // transform 35 registers: 95 spilled.)
+    constexpr bool kSpecInLds = true;
+    double2 *hspec_lds = reinterpret_cast<double2 *>(smem_raw);       // H[0..512] (+ pad)
+    double2 *tws = kSpecInLds ? hspec_lds + kHalf32 + 1 : hspec_lds;  // W1024^(k n), k = 1..31, n = 0..31
+    const double2 *hspec = kSpecInLds ? hspec_lds : hperm_g;
     double *planes = reinterpret_cast<double *>(tws + 31 * 32);   // [waves][2][kPlane32]
-    LocalRec<4 * (S > 0 ? S : 1)> *ring =
-        reinterpret_cast<LocalRec<4 * (S > 0 ? S : 1)> *>(planes + (size_t)kWaves32 * 2 * kPlane32);  // LOCAL only
-    unsigned *round_done = reinterpret_cast<unsigned *>(ring + kLocalRing);  // [4], LOCAL only
+    constexpr int kRingNV = S >= 2 ? 4 : 4 * (S > 0 ? S : 1);      // doubles per record (S >= 2: one ring per section)
+    constexpr int kRings = S >= 2 ? S : 1;
+    constexpr int kRingLen = S >= 2 ? kLocalRing2 : kLocalRing;
+    LocalRec<kRingNV> *ring = reinterpret_cast<LocalRec<kRingNV> *>(planes + (size_t)kWaves32 * 2 * kPlane32);  // LOCAL only
+    unsigned *round_done = reinterpret_cast<unsigned *>(ring + kRings * kRingLen);  // [4], LOCAL only
     if constexpr (LOCAL) {
-        for (int i = threadIdx.x; i < kLocalRing; i += kWaves32 * 64)
+        for (int i = threadIdx.x; i < kRings * kRingLen; i += kWaves32 * 64)
             ring[i].tag = 0;
         if (threadIdx.x < 4)
             round_done[threadIdx.x] = 0;
@@ -702,8 +1027,9 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 
     fir_history_carry(in_base, hist_base, static_cast<typename HistOf<TIn, S>::type *>(a.hist_new), a.frames, a.line_stride,
                       a.H, a.C, a.lines);
-    for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
-        hspec[i] = hperm_g[i];
+    if constexpr (kSpecInLds)
+        for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
+            hspec_lds[i] = hperm_g[i];
     for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
         tws[i] = tw_g[32 + i];
     __syncthreads();
@@ -854,8 +1180,12 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             __builtin_amdgcn_s_setprio(3);
             __builtin_amdgcn_sched_barrier(0);  // the epilogue's early loads stay out of the transform's registers
             // (LOCAL: item index in the workgroup's list = two per unit, Lines padded to whole units)
-            fused_epilogue<S, GENERAL, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
-                                              (int)(2 * unit) + half PH_FPROF_ARGS);
+            if constexpr (S >= 2)
+                fused_epilogue_sections<S, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
+                                                  (int)(2 * unit) + half);
+            else
+                fused_epilogue<S, GENERAL, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
+                                                  (int)(2 * unit) + half PH_FPROF_ARGS);
             __builtin_amdgcn_sched_barrier(0);  // ... and the store addresses are not computed ahead of it
             __builtin_amdgcn_s_setprio(0);
         }

@@ -76,7 +76,9 @@ def oracle_chain(taps, q, g, x):
     (1, 2, 769 * 90, 256, DC_BLOCK, None, [769 * 90]),                 # slow filter: look-back goes to a P record
     (3, 4, 50_000, 100, DC_BLOCK, 1.25, [20_000, 30_000]),             # several windows of 32 predecessors, ragged
     (5, 6, 30_000, 64, TWO_SECTIONS, 0.9, [9_999, 20_001]),            # 2 sections, 3 pairs (units straddle tiles)
-    (2, 2, 40_000, 511, TWO_SECTIONS, None, [40_000]),                 # longest filter: tiles of 514 frames
+    (2, 2, 40_000, 511, TWO_SECTIONS, None, [40_000]),                 # longest filter: tiles of 514 frames; two sections fused
+    (9, 4, 3 * 4096, 256, TWO_SECTIONS, 0.7, [4096, 4096, 4096]),      # two sections, three launches: both sections' slots carry
+    (3, 2, 20_032, 100, TWO_SECTIONS, 1.5, [10_016, 4000, 6016]),      # ... fused, staged (ragged end), fused again
     (7, 16, 5_000, 16, LOWPASS, 2.0, [5_000]),                         # shortest filter, first output in lane 0
 ])
 def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, calls, monkeypatch):
@@ -85,12 +87,10 @@ def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, cal
     rng = np.random.default_rng(7 + lines * 31 + C)
     x = rng.uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
     got, names = run_chain(taps, q, g, x, calls)
-    if len(q) == 1:
-        assert all("chain_fused_kernel" in n for n in names), names
-    else:
-        # cascades of two sections take the staged chain (overlap-save FIR, time-segmented biquad):
-        # the fused kernel's two-section form does not fit a wave's registers (chain_fused.hpp)
-        assert all("chain_fused" not in n for n in names), names
+    # one section: always fused.  Two sections: fused (the sections one after the other over the tile,
+    # ols32_kernel.hpp fused_epilogue_sections) when the Lines end on a segment boundary, else the staged chain
+    for n, name in zip(calls, names):
+        assert ("chain_fused_kernel" in name) == (len(q) == 1 or n % 32 == 0), (n, name)
     assert not np.isnan(got).any()
     worst, differ = 0.0, 0
     for l in sorted({0, lines // 2, lines - 1}):
@@ -144,7 +144,7 @@ def test_full_config3_shape_every_line(monkeypatch):
             assert dd.max() <= 1.0, f"line {l}: {dd.max()} ulp"
 
 
-@pytest.mark.parametrize("q", [LOWPASS, DC_BLOCK], ids=["forgetful", "general"])
+@pytest.mark.parametrize("q", [LOWPASS, DC_BLOCK, TWO_SECTIONS], ids=["forgetful", "general", "two_sections"])
 def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
     """Between two fused launches the cascade's state lives in the plan's tagged slots (written by the
     launch's last tiles when the buffer ends on a segment boundary, frames % 32 == 0, by the tail
@@ -177,7 +177,8 @@ def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
             pos += n
         p.flush()
     got = torch.cat(outs, dim=1).cpu().numpy()
-    assert ["chain_fused" in nm for nm in names] == [not e for _, e in plan], names
+    # (two sections run fused only for Lines that end on a segment boundary)
+    assert ["chain_fused" in nm for nm in names] == [not e and (len(q) == 1 or n % 32 == 0) for n, e in plan], names
     cut = sum(n for n, _ in plan[:restart_before])
     for l in range(lines):
         if restarted[0] <= l <= restarted[1]:
@@ -312,3 +313,51 @@ def test_mutations_between_fused_launches(lines, monkeypatch):
             want.append(O.gain(yk, g2 if k >= 3 else g1).reshape(F, C))
         d = ulps(got[l], np.concatenate(want))
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at frame {np.argmax(d) // C}"
+
+
+SLOW_PLUS_FAST = np.vstack([DC_BLOCK, synth.biquad_rbj_lowpass(2000.0)])
+
+
+def test_two_section_cascade_at_the_config3_shape(monkeypatch):
+    """512 Lines x 8 ch x 4096 frames, FIR-256 -> two-section biquad -> gain: the block-local form with
+    one record ring per section, two launches (both sections' state slots carry).  Every Line against the
+    staged bit-exact chain on the device, 24 Lines against the oracle; the global form on fewer Lines
+    gives the same bits as the local one on the Lines they share."""
+    lines, C, frames, ntaps, g = 512, 8, 4096, 256, 0.7071067811865476
+    taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)
+    x = np.stack([synth.samples(synth.line_seed(1200 + l), 0, 2 * frames * C, np.float32).reshape(2 * frames, C)
+                  for l in range(lines)])
+    got, names = run_chain(taps, TWO_SECTIONS, g, x, [frames, frames])
+    assert all(n == "chain_fused_kernel<f32,f32,fir+biquad2+gain,local>" for n in names), names
+    assert not np.isnan(got).any()
+    exact, enames = run_chain(taps, TWO_SECTIONS, g, x, [frames, frames], exact=True)
+    assert all("chain_fused" not in n for n in enames), enames
+    floor = 2.0 ** -24 * np.abs(exact).max(axis=(1, 2), keepdims=True)
+    mag = np.maximum(np.abs(exact), floor).astype(np.float32)
+    d = np.abs(got.astype(np.float64) - exact.astype(np.float64)) / np.spacing(mag).astype(np.float64)
+    worst = d.reshape(lines, -1).max(axis=1)
+    assert worst.max() <= 1.0, f"line {int(worst.argmax())}: {worst.max()} ulp"
+    differ = (got != exact).reshape(lines, -1).sum(axis=1)
+    assert differ.sum() <= lines * 2 * frames * C * 3 // 100_000, (int(differ.max()), int(differ.sum()))
+    for l in list(range(0, 256, 32)) + list(range(256, 512, 32)) + [1, 255, 257, 511, 100, 356, 200, 456]:
+        dd = ulps(got[l], oracle_chain(taps, TWO_SECTIONS, g, x[l]))
+        assert dd.max() <= 1.0, f"line {l}: {dd.max()} ulp"
+    # the global look-back (fewer Lines than CUs) on the first 40 Lines: the same sums in the same order
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    got40, names40 = run_chain(taps, TWO_SECTIONS, g, x[:40], [frames, frames])
+    assert all(n == "chain_fused_kernel<f32,f32,fir+biquad2+gain>" for n in names40), names40
+    assert np.array_equal(got40, got[:40])
+
+
+def test_two_sections_with_a_slow_one_take_the_staged_chain(monkeypatch):
+    """A DC blocker next to a low-pass: the blocker does not forget within a look-back window, and the
+    two-section form has no general look-back -- the staged chain runs, within the same tolerance."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, frames = 3, 4, 20_480
+    taps = synth.fir_lowpass_taps(128, f32_rounded=True)
+    x = np.random.default_rng(5).uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
+    got, names = run_chain(taps, SLOW_PLUS_FAST, None, x, [frames])
+    assert all("chain_fused" not in n for n in names), names
+    for l in range(lines):
+        d = ulps(got[l], oracle_chain(taps, SLOW_PLUS_FAST, None, x[l]))
+        assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
