@@ -350,6 +350,15 @@ def run_rank(args, rank, world, local, sync, launch):
         fir.set_exact(False)
         exact_ms = ems / max(en, 1)
 
+    # Short launches (configs 2 / 3: 0.07 - 0.35 ms a step) read the clock ramp unless the device is busy
+    # for a while first (the first launches after an idle period run 10 - 25 % slow, docs/NOTEBOOK.md
+    # section 4); config 1's bit-exact leg above is that load already.  Untimed, before the W warm-up steps.
+    if cfg != 1:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.25:
+            for _ in range(50):
+                proc.process_batch(d_in, d_out, frames_per_line, stream=stream)
+            torch.cuda.synchronize(dev)
     elapsed, kernel_ms, launches, kname = timed(proc, args.steps, args.warmup, d_in, d_out, frames_per_line,
                                                 barrier=True)
     elapsed = sync.max(elapsed)

@@ -1,0 +1,37 @@
+#!/bin/bash
+# On the GPU box: everything profiles/ holds for a round, in one call.
+#   scripts/gpu_collect_round.sh r03
+# (builds the instrumented / ablation libraries first if they are missing; they are never shipped)
+set -u
+TAG=${1:-r03}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+bash scripts/gpu_profile_all.sh $TAG > $OUT/profile_all.log 2>&1
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+for c in 2 3; do python bench.py --config $c --no-cpu-baseline > $OUT/bench_c$c.json 2>/dev/null; done
+python scripts/bench_hostcall.py > $OUT/hostcall.jsonl 2>/dev/null
+python scripts/bench_configs.py > $OUT/configs_untraced.jsonl 2>/dev/null
+bash scripts/gpu_fetch_calib.sh > $OUT/calib.log 2>&1
+cp gpurun_out/prof/fetch_calib.txt $OUT/fetch_calibration.txt
+# in-kernel phase profiles (instrumented builds)
+if [ -f pipe_amd/lib/libpipe_hip_prof.so ]; then
+  PIPE_HIP_LIB=$PWD/pipe_amd/lib/libpipe_hip_prof.so python scripts/chain_probe.py 50 > $OUT/fused_chain_phase_profile.txt 2>&1
+  PROBE_SECTIONS=2 PIPE_HIP_LIB=$PWD/pipe_amd/lib/libpipe_hip_prof.so python scripts/chain_probe.py 50 >> $OUT/fused_chain_phase_profile.txt 2>&1
+fi
+if [ -f pipe_amd/lib/libpipe_hip_rsprof.so ]; then
+  PIPE_HIP_LIB=$PWD/pipe_amd/lib/libpipe_hip_rsprof.so python scripts/resampler_probe.py 40 > $OUT/resampler_phase_profile.txt 2>&1
+fi
+python scripts/resampler_probe.py 3000 > $OUT/resampler_probe.txt 2>&1
+PIPE_HIP_RESAMPLE_NO_PAIR=1 python scripts/resampler_probe.py 3000 >> $OUT/resampler_probe.txt 2>&1
+python scripts/chain_probe.py > $OUT/chain_probe.txt 2>&1
+PROBE_SECTIONS=2 python scripts/chain_probe.py >> $OUT/chain_probe.txt 2>&1
+PROBE_SECTIONS=2 PIPE_HIP_CHAIN_ONE_SECTION=1 python scripts/chain_probe.py >> $OUT/chain_probe.txt 2>&1
+for n in 512 1024 2048 4096; do
+  python bench.py --taps $n --no-secondary --no-cpu-baseline --no-live-pmc --steps 20 --warmup 3 --buffers 32768 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(json.dumps({'taps': $n, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg_kernel_ms'], 'gsamples_per_s': round(d['value']/1e3,1), 'bit_exact_gsamples_per_s': round(d['bit_exact_form']['msamples_per_s']/1e3,1)}))" >> $OUT/long_fir.jsonl
+done
+SEC=3 bash scripts/gpu_energy_table.sh > $OUT/energy.log 2>&1
+cp gpurun_out/energy/table.txt $OUT/energy_table.txt
+grep -v amdgpu $OUT/chain_probe.txt; cat $OUT/long_fir.jsonl; tail -4 $OUT/hostcall.jsonl; tail -12 $OUT/energy_table.txt
