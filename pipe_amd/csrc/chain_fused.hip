@@ -361,7 +361,8 @@ bool Plan::accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipSt
 {
     if (S == 1)
         return true;
-    if (S != 2 || frames % 32 != 0 || std::getenv("PIPE_HIP_CHAIN_GENERAL") || std::getenv("PIPE_HIP_CHAIN_ONE_SECTION"))
+    (void)frames;
+    if (S != 2 || std::getenv("PIPE_HIP_CHAIN_GENERAL") || std::getenv("PIPE_HIP_CHAIN_ONE_SECTION"))
         return false;
     if (prepare(coeffs, S, ntaps, s) != PIPE_HIP_OK)
         return false;
@@ -618,7 +619,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
     static const bool force_general = std::getenv("PIPE_HIP_CHAIN_GENERAL") != nullptr;
     const bool general = force_general || I.D > 32;
-    if (S < 1 || S > kMaxFusedSections || (S == 2 && (general || frames % 32 != 0)))
+    if (S < 1 || S > kMaxFusedSections || (S == 2 && general))
         return PIPE_HIP_EINVAL;  // (Plan::accepts said otherwise: the caller did not ask)
     I.c1.gain = I.c2.gain = has_gain ? gain : 1.0;
     // Block-local look-back (ols32_kernel.hpp): at least as many Lines as CUs -- a workgroup per CU,
@@ -643,8 +644,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
             *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
             PH_TRY((launch<2, false, false>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
         }
-        return PIPE_HIP_OK;
-    }
+    } else
     if (general) {
         I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
         *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
@@ -676,8 +676,12 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.epoch = I.epoch;
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
-        hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                           static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c1);
+        if (S == 2)
+            hipLaunchKernelGGL(chain_tail_kernel<2>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c2);
+        else
+            hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c1);
         PH_HIP(hipGetLastError());
     }
     return PIPE_HIP_OK;

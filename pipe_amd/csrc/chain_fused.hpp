@@ -33,7 +33,7 @@ public:
     // the fused kernel's workgroup (512 threads + its LDS) fits a CU of the current device
     static bool launchable();
     // this cascade on a call of `frames` frames: one section always; two sections when every section
-    // forgets within a look-back window and the Lines end on a segment boundary (frames % 32 == 0)
+    // forgets within a look-back window
     bool accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipStream_t s);
     // EHIP if a launch since the last poll gave up waiting for a predecessor tile.  The caller has
     // synchronised the launch stream; this is a read of a pinned flag.

@@ -692,9 +692,8 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
 // look-back and the ordered recurrence over it in place (channel 0 in registers, channel 1 in the
 // plane), with its own matrices, records and state slots, and the tile goes back to natural layout
 // ONCE.  The arithmetic per section is exactly the one-section epilogue's: same contract
-// (tests/test_gpu_chain_fused.py).  Forgetful filters only (every section forgets within kLocalReach
-// tiles: all audio EQs); Lines that end on a segment boundary only (the host checks both and takes the
-// staged chain otherwise).
+// (tests/test_gpu_chain_fused.py).  Forgetful filters only (every section forgets within a look-back
+// window: all audio EQs; the host checks and takes the staged chain otherwise).
 //   fa.mats : [S][kMatCount] 2 x 2 matrices, section-major
 //   records : [series][tile][A | P][2 NV granules], NV = 4 S: section k's aggregate at doubles
 //             2k, 2k + 1 (channel 0) and 2S + 2k, 2S + 2k + 1 (channel 1)
@@ -744,6 +743,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
     // the state slot of this launch's readers / writer: the tags decide once for all sections
     const bool mine_first = valid && tile - 1 - l5 == -1 && l5 < fc.D;  // this lane stands for "tile -1"
     const bool ends_here = valid && last_tile && l5 == ((a.HP + len - 1) >> 5);
+    const bool on_boundary = ((a.HP + len) & 31) == 0;
 
     for_each_section<S>([&](auto sec_c) {
         constexpr int SEC = decltype(sec_c)::value;
@@ -939,6 +939,14 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
             affine<1>(str, er, pk, sr);
             affine<1>(sti, ei, pk, si);
         }
+        if (ends_here && !on_boundary) {  // the Line ends inside this segment: chain_tail_kernel walks it from here
+            double *sp = fa.seg_state + series * NV;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sp[2 * SEC + j] = str[j];
+                sp[2 * S + 2 * SEC + j] = sti[j];
+            }
+        }
         {
             double xi[32];
 #pragma unroll
@@ -954,7 +962,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
                     xi[c] = biquad_step1(xi[c], sti, cf);
                 }
             }
-            if (ends_here) {  // (the host launches this form only for Lines that end on a segment boundary)
+            if (ends_here && on_boundary) {  // the Line ends where this segment ends: its state after the loop
                 unsigned long long *dst = own_write_slot<NV>(own_base, fa.epoch);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {

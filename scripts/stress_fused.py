@@ -19,7 +19,7 @@ torch.cuda.set_stream(torch.cuda.Stream())
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 filters = [synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(3000.0), np.array([[1.0, -1.0, 0.0, -0.9995, 0.0]]),
-           # two sections (fused for Lines that end on a segment boundary: one ring of records per section)
+           # two sections (one ring of records per section)
            np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0)]),
            np.vstack([synth.biquad_rbj_lowpass(5000.0, q=0.5), synth.biquad_rbj_lowpass(1500.0)])]
 
@@ -54,7 +54,7 @@ for it in range(iters):
     ncalls = int(rng.integers(1, 4))
     budget = 40_000_000 // (lines * C)          # samples per Line that keep the case small
     calls = [int(rng.integers(700, max(800, min(9000, budget // ncalls)))) for _ in range(ncalls)]
-    if rng.random() < 0.5 or (len(q) == 2 and rng.random() < 0.8):
+    if rng.random() < 0.5:
         calls = [c // 32 * 32 for c in calls]   # buffers that end on a segment boundary: no tail kernel
     frames = sum(calls)
     taps = synth.fir_lowpass_taps(ntaps, f32_rounded=True)

@@ -78,7 +78,7 @@ def oracle_chain(taps, q, g, x):
     (5, 6, 30_000, 64, TWO_SECTIONS, 0.9, [9_999, 20_001]),            # 2 sections, 3 pairs (units straddle tiles)
     (2, 2, 40_000, 511, TWO_SECTIONS, None, [40_000]),                 # longest filter: tiles of 514 frames; two sections fused
     (9, 4, 3 * 4096, 256, TWO_SECTIONS, 0.7, [4096, 4096, 4096]),      # two sections, three launches: both sections' slots carry
-    (3, 2, 20_032, 100, TWO_SECTIONS, 1.5, [10_016, 4000, 6016]),      # ... fused, staged (ragged end), fused again
+    (3, 2, 20_032, 100, TWO_SECTIONS, 1.5, [10_016, 4000, 6016]),      # ... a ragged end in the middle (tail kernel, two sections)
     (7, 16, 5_000, 16, LOWPASS, 2.0, [5_000]),                         # shortest filter, first output in lane 0
 ])
 def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, calls, monkeypatch):
@@ -87,10 +87,9 @@ def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, cal
     rng = np.random.default_rng(7 + lines * 31 + C)
     x = rng.uniform(-1, 1, size=(lines, frames, C)).astype(np.float32)
     got, names = run_chain(taps, q, g, x, calls)
-    # one section: always fused.  Two sections: fused (the sections one after the other over the tile,
-    # ols32_kernel.hpp fused_epilogue_sections) when the Lines end on a segment boundary, else the staged chain
-    for n, name in zip(calls, names):
-        assert ("chain_fused_kernel" in name) == (len(q) == 1 or n % 32 == 0), (n, name)
+    # one section and two forgetful sections (the sections one after the other over the tile,
+    # ols32_kernel.hpp fused_epilogue_sections): fused, whether or not the Lines end on a segment boundary
+    assert all("chain_fused_kernel" in n for n in names), names
     assert not np.isnan(got).any()
     worst, differ = 0.0, 0
     for l in sorted({0, lines // 2, lines - 1}):
@@ -177,8 +176,7 @@ def test_cascade_state_survives_every_change_of_form(q, monkeypatch):
             pos += n
         p.flush()
     got = torch.cat(outs, dim=1).cpu().numpy()
-    # (two sections run fused only for Lines that end on a segment boundary)
-    assert ["chain_fused" in nm for nm in names] == [not e and (len(q) == 1 or n % 32 == 0) for n, e in plan], names
+    assert ["chain_fused" in nm for nm in names] == [not e for _, e in plan], names
     cut = sum(n for n, _ in plan[:restart_before])
     for l in range(lines):
         if restarted[0] <= l <= restarted[1]:
