@@ -166,8 +166,8 @@ def live_pmc(args, want):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
-            cmd = ["timeout", "-k", "5", "240", "rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            cmd = ["timeout", "-k", "5", "90", "rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             per = {}
             for p in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                 db = sqlite3.connect(p)
