@@ -2,6 +2,9 @@
 // handle that every Processor kind shares: device selection, the handle's stream,
 // pinned/device staging for the host-pointer ProcessFunc form, and the hipEvent
 // bracket used for live kernel timing.
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -551,6 +554,16 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
         }();
         const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD");
         c.bar = large_bar != 0 && !(e && e[0] == '0');
+        if (c.bar) {
+            // ... and the staging buffer really is in this process's address space (the attribute is a
+            // device property; a platform that reports it without mapping allocations must not be
+            // written to): mincore fails with ENOMEM on an unmapped range and touches nothing
+            const long page = sysconf(_SC_PAGESIZE);
+            unsigned char vec = 0;
+            void *first = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(c.d_in) & ~(uintptr_t)(page - 1));
+            if (page <= 0 || mincore(first, (size_t)page, &vec) != 0)
+                c.bar = false;
+        }
     }
     c.trace = std::getenv("PIPE_HIP_OVERLAP_TRACE") != nullptr;  // debug: where a call's time goes
     c.t0 = std::chrono::steady_clock::now();
