@@ -20,6 +20,7 @@
 // Infinity-Cache traffic.  Same contract as the one-spectrum form: float64 arithmetic, the float32
 // result within one ulp of the oracle's ordered sum at the filter's full scale
 // (tests/test_gpu_fir_ols.py).
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -246,7 +247,27 @@ struct ArgsD {
     int64_t nunits;
     const double2 *hpart; // [P][kHalf32 + 1]
     double2 *ring;        // [waves][P][32 registers][64 lanes]
+    unsigned long long *prof;  // PH_OLSD_PROF builds: [wave][kProfD] s_memtime ticks per phase
 };
+[[maybe_unused]] constexpr int kProfD = 6;
+// measurement builds (scripts/build_ablate_lib.sh fir_ols32p PH_OLSD_ABLATE ...): bit 0 no output stores,
+// bit 1 no ring stores, bit 2 ring loads replaced by arithmetic, bit 3 tap-spectrum loads likewise,
+// bit 4 no window loads.  Wrong results by construction.
+#ifndef PH_OLSD_ABLATE
+#define PH_OLSD_ABLATE 0
+#endif
+#ifdef PH_OLSD_PROF
+#define PH_D_STAMP(i)                                                 \
+    do {                                                              \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        dprof[i] += now_ - dlast;                                     \
+        dlast = now_;                                                 \
+    } while (0)
+#else
+#define PH_D_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
 
 template <typename TIn, typename TOut>
 __global__ void __launch_bounds__(kWaves32 * 64)
@@ -256,11 +277,16 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double2 *tws = reinterpret_cast<double2 *>(smem_raw);
     double *planes = reinterpret_cast<double *>(tws + 31 * 32);
+    // partition 0's tap spectrum: every tile of every wave multiplies by it, and it is all the LDS
+    // left over holds (the other partitions' come through L2)
+    double2 *h0s = reinterpret_cast<double2 *>(planes + (size_t)kWaves32 * 2 * kPlane32);
     const Args32 &a = t.a;
 
     fir_history_carry(in_base, hist_base, static_cast<double *>(a.hist_new), a.frames, a.line_stride, a.H, a.C, a.lines);
     for (int i = threadIdx.x; i < 31 * 32; i += kWaves32 * 64)
         tws[i] = tw_g[32 + i];
+    for (int i = threadIdx.x; i < kHalf32; i += kWaves32 * 64)
+        h0s[i] = t.hpart[i];
     __syncthreads();
 
     const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -278,6 +304,9 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
     auto bytes31 = [](int64_t n) { return (int)(n < 0 ? 0 : (n < 0x7FFFFFFF ? n : 0x7FFFFFFF)); };
     const int64_t last = a.frames - 1;
     constexpr int kL = 512;  // hop = partition = window overlap
+#ifdef PH_OLSD_PROF
+    unsigned dprof[kProfD] = {}, dlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
 
     for (int64_t unit = wave_global; unit < t.nunits; unit += wave_stride) {
         // unit -> (series, pair of runs): half h runs tiles [tb, te) of series (line, pair)
@@ -317,8 +346,14 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                 asm volatile("" : "+v"(v0));
                 In2 pf[32];
 #pragma unroll
-                for (int r = 0; r < 32; ++r)
-                    pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+                for (int r = 0; r < 32; ++r) {
+                    if (PH_OLSD_ABLATE & 16) {
+                        pf[r].x = (TIn)(v0 + r);
+                        pf[r].y = (TIn)(v0 - r);
+                    } else {
+                        pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 32; ++r)
                     PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
@@ -344,23 +379,29 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                     PH_NAT(r) = cd{re, im};
                 }
             }
+            // (no stamp between the window and its transform: one there costs the build its registers)
             ols32_forward(lo, hi, pa, pb, twl);
             __builtin_amdgcn_sched_barrier(0);
+            PH_D_STAMP(1);
             // ---- into the ring; for a tile of the run: Y = sum_p X_{t-p} H_p ----------------------------
             double2 *__restrict__ slot_cur = wave_ring + (int64_t)cur * (32 * 64) + lane;
-            const double2 *__restrict__ hp0 = t.hpart;
+            const double2 *hp0 = h0s;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 double2 h[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k1 = 4 * g + i;
-                    h[i] = k1 < 16 ? hp0[32 * k1 + l5] : hp0[1024 - 32 * k1 - l5];
+                    if (PH_OLSD_ABLATE & 8)
+                        h[i] = double2{(double)(l5 + k1), 0.5};
+                    else
+                        h[i] = k1 < 16 ? hp0[32 * k1 + l5] : hp0[1024 - 32 * k1 - l5];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k1 = 4 * g + i;
-                    slot_cur[k1 * 64] = double2{PH_SPL(k1).re, PH_SPL(k1).im};
+                    if (!(PH_OLSD_ABLATE & 2) || PH_SPL(k1).re == 1234.5)
+                        slot_cur[k1 * 64] = double2{PH_SPL(k1).re, PH_SPL(k1).im};
                     if constexpr (!WARM) {
                         const cd w{h[i].x, k1 < 16 ? h[i].y : -h[i].y};
                         PH_SPL(k1) = cmul(PH_SPL(k1), w);
@@ -368,6 +409,7 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            PH_D_STAMP(2);
             if constexpr (WARM)
                 return;
 #pragma unroll 1
@@ -377,27 +419,42 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                 const int sp = cur - p < 0 ? cur - p + t.P : cur - p;
                 const double2 *__restrict__ xs = wave_ring + (int64_t)sp * (32 * 64) + lanep;
                 const double2 *__restrict__ hp = t.hpart + (size_t)p * (kHalf32 + 1);
+                // (group g + 1 is requested before group g's products: two round trips in flight)
+                double2 hq[2][4], xq[2][4];
+                auto fetch = [&](int g, double2 *hd, double2 *xd) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k1 = 4 * g + i;
+                        if (PH_OLSD_ABLATE & 8)
+                            hd[i] = double2{(double)(l5p + k1), 0.5};
+                        else
+                            hd[i] = k1 < 16 ? hp[32 * k1 + l5p] : hp[1024 - 32 * k1 - l5p];
+                        if (PH_OLSD_ABLATE & 4)
+                            xd[i] = double2{(double)(lanep - k1), 0.25};
+                        else
+                            xd[i] = xs[k1 * 64];
+                    }
+                };
+                fetch(0, hq[0], xq[0]);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    double2 h[4], x[4];
+                    if (g + 1 < 8)
+                        fetch(g + 1, hq[(g + 1) & 1], xq[(g + 1) & 1]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k1 = 4 * g + i;
-                        h[i] = k1 < 16 ? hp[32 * k1 + l5p] : hp[1024 - 32 * k1 - l5p];
-                        x[i] = xs[k1 * 64];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k1 = 4 * g + i;
-                        const cd w{h[i].x, k1 < 16 ? h[i].y : -h[i].y};
-                        const cd v = cmul(cd{x[i].x, x[i].y}, w);
+                        const double2 hh = hq[g & 1][i], xx = xq[g & 1][i];
+                        const cd w{hh.x, k1 < 16 ? hh.y : -hh.y};
+                        const cd v = cmul(cd{xx.x, xx.y}, w);
                         PH_SPL(k1).re += v.re;
                         PH_SPL(k1).im += v.im;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            PH_D_STAMP(3);
             ols32_inverse_plain(lo, hi, pa, pb, twl);
+            PH_D_STAMP(4);
             // ---- store: window index i >= 512 is frame tile * 512 + i - 512 -----------------------------
             {
                 const int64_t t00 = (int64_t)tile0 * kL;
@@ -409,9 +466,12 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int off = o0 + r * (int)out_step;
+                    if ((PH_OLSD_ABLATE & 1) && PH_NAT(r).re != 1234.5)
+                        continue;
                     buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
                 }
             }
+            PH_D_STAMP(5);
         };
 #pragma unroll 1
         for (int rel = 1 - t.P; rel < 0; ++rel)
@@ -420,6 +480,13 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
         for (int rel = 0; rel < t.R; ++rel)
             step(rel, std::false_type{});
     }
+#ifdef PH_OLSD_PROF
+    if (t.prof && lane_ == 0) {
+        unsigned long long *dst = t.prof + ((size_t)blockIdx.x * kWaves32 + wave_u) * kProfD;
+        for (int i = 0; i < kProfD; ++i)
+            dst[i] = dprof[i];
+    }
+#endif
 }
 
 template <typename TIn, typename TOut>
@@ -427,7 +494,7 @@ int launch32d(const Plan::Impl &I, const void *d_in, void *d_out, const double *
               KernelTimer *timer)
 {
     auto kfn = fir_ols32d_kernel<TIn, TOut>;
-    const size_t lds = sizeof(double2) * (31 * 32) + sizeof(double) * (size_t)kPlane32 * 2 * kWaves32;
+    const size_t lds = sizeof(double2) * (31 * 32 + kHalf32 + 1) + sizeof(double) * (size_t)kPlane32 * 2 * kWaves32;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     const int64_t wanted = (t.nunits + kWaves32 - 1) / kWaves32;
@@ -435,9 +502,34 @@ int launch32d(const Plan::Impl &I, const void *d_in, void *d_out, const double *
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     if (timer)
         PH_TRY(timer->pair(&ev_a, &ev_b));
+#ifdef PH_OLSD_PROF
+    static DevBuf prof;
+    const size_t nw = (size_t)grid * kWaves32;
+    if (!prof.p)
+        PH_TRY(prof.alloc(sizeof(unsigned long long) * kProfD * kWaves32 * 4096));
+    t.prof = static_cast<unsigned long long *>(prof.p);
+#endif
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const TIn *>(d_in),
                           static_cast<TOut *>(d_out), hist, static_cast<const double2 *>(I.tw32.p), t);
     PH_HIP(hipGetLastError());
+#ifdef PH_OLSD_PROF
+    static int shown = 0;
+    if (shown++ == 3) {  // (a warm launch)
+        PH_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nw * kProfD);
+        PH_HIP(hipMemcpy(h.data(), t.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        static const char *names[kProfD] = {"-", "window + forward", "ring store + H0", "ring loads + Hp", "inverse transform", "output stores"};
+        double sum[kProfD] = {}, tot = 0;
+        for (size_t w = 0; w < nw; ++w)
+            for (int i = 0; i < kProfD; ++i)
+                sum[i] += (double)h[w * kProfD + i];
+        for (int i = 0; i < kProfD; ++i)
+            tot += sum[i];
+        std::fprintf(stderr, "[fir delay-line prof] s_memtime ticks per wave, %zu waves, P = %d, R = %d\n", nw, t.P, t.R);
+        for (int i = 0; i < kProfD; ++i)
+            std::fprintf(stderr, "[fir delay-line prof]   %-20s %10.1f  %5.1f %%\n", names[i], sum[i] / (double)nw, 100.0 * sum[i] / tot);
+    }
+#endif
     return PIPE_HIP_OK;
 }
 
