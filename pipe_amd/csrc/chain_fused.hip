@@ -530,6 +530,30 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
                 std::fprintf(stderr, "[fused prof]   wave %d: transform %8.0f  segments %6.0f  wait %7.0f  pass3 %6.0f  stores %6.0f  total %8.0f\n", w,
                              ph[0] / grid, ph[1] / grid, ph[11] / grid, ph[6] / grid, ph[9] / grid, t / grid);
             }
+#ifdef PH_FUSE_TIMELINE
+            // timeline of two workgroups: ticks since the workgroup's first event
+            std::vector<unsigned long long> tl((size_t)ols::kTlEvents * ols::kTlUnits * kWaves32 * grid);
+            PH_HIP(hipMemcpy(tl.data(), fa.prof + ols::kTlOffset, sizeof(unsigned long long) * tl.size(), hipMemcpyDeviceToHost));
+            for (unsigned b : {0u, grid / 2}) {
+                const unsigned long long *row = tl.data() + (size_t)b * kWaves32 * ols::kTlUnits * ols::kTlEvents;
+                unsigned long long t0 = ~0ull;
+                for (int i = 0; i < kWaves32 * ols::kTlUnits * ols::kTlEvents; ++i)
+                    if (row[i] && row[i] < t0)
+                        t0 = row[i];
+                std::fprintf(stderr, "[fused prof] timeline of workgroup %u (gate | start | transform done | epilogue done | stores issued):\n", b);
+                for (int w = 0; w < kWaves32; ++w) {
+                    std::fprintf(stderr, "[fused prof]   wave %d:", w);
+                    for (int u = 0; u < ols::kTlUnits; ++u) {
+                        const unsigned long long *e = row + ((size_t)w * ols::kTlUnits + u) * ols::kTlEvents;
+                        if (!e[1])
+                            continue;
+                        std::fprintf(stderr, "  [%6lld %6lld %6lld %6lld %6lld]", (long long)(e[0] - t0), (long long)(e[1] - t0),
+                                     (long long)(e[2] - t0), (long long)(e[3] - t0), (long long)(e[4] - t0));
+                    }
+                    std::fprintf(stderr, "\n");
+                }
+            }
+#endif
         }
     }
 #endif
@@ -610,8 +634,11 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     fa.err = I.err_dev;
 #ifdef PH_FUSE_PROF
     if (!I.prof.p)
-        PH_TRY(I.prof.alloc(sizeof(unsigned long long) * ols::kFuseProfPhases * kWaves32 * 4096));
+        PH_TRY(I.prof.alloc(sizeof(unsigned long long) * (ols::kTlOffset + (size_t)ols::kTlEvents * ols::kTlUnits * kWaves32 * 4096)));
     fa.prof = static_cast<unsigned long long *>(I.prof.p);
+#ifdef PH_FUSE_TIMELINE
+    PH_HIP(hipMemsetAsync(fa.prof + ols::kTlOffset, 0, sizeof(unsigned long long) * ols::kTlEvents * ols::kTlUnits * kWaves32 * 4096, s));
+#endif
 #endif
     I.err_checked = false;
     I.last_stream = s;

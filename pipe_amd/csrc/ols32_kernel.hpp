@@ -31,7 +31,26 @@ constexpr int kFuseProfPhases = 13;
     } while (0)
 #define PH_FPROF_PARAMS , unsigned long long (&fprof_acc)[kFuseProfPhases], unsigned long long &fprof_last
 #define PH_FPROF_ARGS , fprof_acc, fprof_last
+// ... and, with -DPH_FUSE_TIMELINE on top, a timeline: absolute s_memtime of five events of each
+// wave's first kTlUnits units (before the round gate, unit start, transform done, epilogue done, stores
+// issued), behind the phase sums.  (Its stores sit in the waves' vmcnt order: the phase sums of such a
+// build are distorted, read only the timeline from it.)
+constexpr int kTlEvents = 5, kTlUnits = 4;
+constexpr size_t kTlOffset = (size_t)kFuseProfPhases * 8 * 4096;
+#endif
+#if defined(PH_FUSE_PROF) && defined(PH_FUSE_TIMELINE)
+#define PH_FTIME(ev)                                                                                         \
+    do {                                                                                                     \
+        if (fa.prof && tl_unit < kTlUnits && lane == 0)                                                      \
+            fa.prof[kTlOffset + (((size_t)blockIdx.x * 8 + wave) * kTlUnits + tl_unit) * kTlEvents + (ev)] = \
+                __builtin_amdgcn_s_memtime();                                                                \
+    } while (0)
 #else
+#define PH_FTIME(ev) \
+    do {             \
+    } while (0)
+#endif
+#ifndef PH_FUSE_PROF
 #define PH_FSTAMP(i) \
     do {             \
     } while (0)
@@ -1084,7 +1103,6 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const unsigned in_step = (unsigned)(32 * a.C * sizeof(TIn));    // 32 frames
     const unsigned out_step = (unsigned)(32 * a.C * sizeof(TOut));
     auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
-    const int64_t last = a.frames - 1;
 
 #ifdef PH_FUSE_PROF
     unsigned long long fprof_acc[kFuseProfPhases] = {};
@@ -1099,7 +1117,15 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             ++round;
         }
     };
+#ifdef PH_FUSE_PROF
+    int tl_unit = -1;
+#endif
     for (int64_t unit = wave_global; unit < unit_end; unit += wave_stride) {
+#ifdef PH_FUSE_PROF
+        ++tl_unit;
+        if constexpr (S > 0)
+            PH_FTIME(0);
+#endif
         if constexpr (LOCAL) {
             if (round >= 2) {  // everybody is through round - 2 (its count: 8 per pass over the four counters)
                 const unsigned want = (unsigned)kWaves32 * (unsigned)((round - 2) / 4 + 1);
@@ -1112,6 +1138,10 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 continue;
             }
         }
+#ifdef PH_FUSE_PROF
+        if constexpr (S > 0)
+            PH_FTIME(1);
+#endif
         // ---- the unit's two items: item0 = 2 slot (half 0), item0 + 1 (half 1) -----------------
         const int item0 = 2 * slot;
         const int tile0 = __builtin_amdgcn_readfirstlane(item0 / a.pairs);
@@ -1142,27 +1172,45 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             for (int r = 0; r < 32; ++r)
                 PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
         } else {
-            // a Line's first tile: its head is the history
-            const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
-            const typename HistOf<TIn, S>::type *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
-            const int64_t fr0 = (int64_t)tile * a.L - a.HP;
+            // a Line's first tile: its head is the history.  Branch-free, two batches of requests (a
+            // window's first 512 indices may reach back into the history, the rest never do): frames
+            // outside the Line and the history read as zero through the resources' bounds.  (One load
+            // per branch of an if / else ladder was 32 dependent round trips: the first tile of a Line
+            // heads the fused chain's look-back order, and everybody behind it waited.)
+            using THist = typename HistOf<TIn, S>::type;
+            using H2 = typename Pair<THist>::type;
+            const TIn *in0 = in_base + (int64_t)line * a.line_stride;
+            const THist *hist0 = hist_base + (int64_t)line * a.H * a.C;
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<TIn *>(in0), 0, bytes31(a.frames * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<THist *>(hist0), 0, bytes31((int64_t)a.H * a.C * (int64_t)sizeof(THist)), 0x00020000);
+            const int fr0 = tile * a.L - a.HP;  // (first tiles: small)
+            {
+                In2 pi[16];
+                H2 ph[16];
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int64_t g = fr0 + l5 + 32 * r;
-                double re = 0.0, im = 0.0;
-                if (valid) {
-                    if (g >= 0) {
-                        if (g <= last) {
-                            re = (double)in[g * a.C + c0];
-                            im = (double)in[g * a.C + c0 + 1];
-                        }
-                    } else if (g >= -(int64_t)a.H) {  // (frames further back only reach positions
-                                                      //  without output when HP > H)
-                        re = (double)hist[(g + a.H) * a.C + c0];
-                        im = (double)hist[(g + a.H) * a.C + c0 + 1];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int g = fr0 + l5 + 32 * r;
+                    pi[r] = buf_load_pair<TIn>(rin, valid && g >= 0 ? (unsigned)((g * a.C + c0) * (int)sizeof(TIn)) : kOut32);
+                    ph[r] = buf_load_pair<THist>(rh, valid && g < 0 && g >= -a.H ? (unsigned)(((g + a.H) * a.C + c0) * (int)sizeof(THist)) : kOut32);
                 }
-                PH_NAT(r) = cd{re, im};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = fr0 + l5 + 32 * r;
+                    PH_NAT(r) = g >= 0 ? cd{(double)pi[r].x, (double)pi[r].y} : cd{(double)ph[r].x, (double)ph[r].y};
+                }
+            }
+            {
+                In2 pi[16];
+#pragma unroll
+                for (int r = 16; r < 32; ++r) {
+                    const int g = fr0 + l5 + 32 * r;  // >= 0: HP <= 511
+                    pi[r - 16] = buf_load_pair<TIn>(rin, valid ? (unsigned)((g * a.C + c0) * (int)sizeof(TIn)) : kOut32);
+                }
+#pragma unroll
+                for (int r = 16; r < 32; ++r)
+                    PH_NAT(r) = cd{(double)pi[r - 16].x, (double)pi[r - 16].y};
             }
         }
         // the next unit's coordinates (uniform)
@@ -1183,6 +1231,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         ols32_transform(lo, hi, pa, pb, twl, hlo, hhi);
         if constexpr (S > 0) {
             PH_FSTAMP(0);  // window + FIR transform
+            PH_FTIME(2);
             // The epilogue is chains of dependent fma and round trips, a few instructions each: they
             // go ahead of the other wave's dense transform on this SIMD, which loses nothing by it.
             __builtin_amdgcn_s_setprio(3);
@@ -1196,6 +1245,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                                                   (int)(2 * unit) + half PH_FPROF_ARGS);
             __builtin_amdgcn_sched_barrier(0);  // ... and the store addresses are not computed ahead of it
             __builtin_amdgcn_s_setprio(0);
+            PH_FTIME(3);
         }
 
         // ---- store the valid part: window index i >= H is frame t0 + i - H --------------------
@@ -1213,8 +1263,10 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             }
         }
 #ifdef PH_FUSE_PROF
-        if constexpr (S > 0)
+        if constexpr (S > 0) {
             PH_FSTAMP(9);  // stores
+            PH_FTIME(4);
+        }
 #endif
         end_round();
     }
