@@ -302,7 +302,6 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
     // (a step past the end of the Line bases its resources beyond the Line: zero records, so that the
     // out-of-range offset of its lanes IS out of range)
     auto bytes31 = [](int64_t n) { return (int)(n < 0 ? 0 : (n < 0x7FFFFFFF ? n : 0x7FFFFFFF)); };
-    const int64_t last = a.frames - 1;
     constexpr int kL = 512;  // hop = partition = window overlap
 #ifdef PH_OLSD_PROF
     unsigned dprof[kProfD] = {}, dlast = (unsigned)__builtin_amdgcn_s_memtime();
@@ -357,10 +356,13 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
 #pragma unroll
                 for (int r = 0; r < 32; ++r)
                     PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
-            } else {
+            } else if constexpr (sizeof(TIn) == 8) {
+                // the window reaches back into the history; float64 input: the plain ladder (the batched
+                // form below costs this variant, whose window alone is 128 registers, 40 bytes of scratch)
                 const TIn *__restrict__ in = in_base + (int64_t)line * a.line_stride;
                 const double *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C;
                 const int64_t fr0 = (int64_t)tile * kL - kL;
+                const int64_t last = a.frames - 1;
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int64_t g = fr0 + l5 + 32 * r;
@@ -377,6 +379,35 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                         }
                     }
                     PH_NAT(r) = cd{re, im};
+                }
+            } else {
+                // the window reaches back into the history (warm-up steps, a Line's first tile): branch-free,
+                // batches of requests -- input AND history for every index, the one out of range
+                // reading zero through its resource's bounds, then a select (a load per branch of an
+                // if / else ladder is 32 dependent round trips, and short Lines start with P of these)
+                const TIn *in0 = in_base + (int64_t)line * a.line_stride;
+                const double *hist0 = hist_base + (int64_t)line * a.H * a.C;
+                const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(in0), 0, bytes31(a.frames * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double *>(hist0), 0, bytes31((int64_t)a.H * a.C * (int64_t)sizeof(double)), 0x00020000);
+                const int fr0 = tile * kL - kL;  // (runs that start at a Line's head: small)
+                constexpr int kB = 8;
+#pragma unroll
+                for (int b = 0; b < 32 / kB; ++b) {
+                    In2 pi[kB];
+                    double2 ph[kB];
+#pragma unroll
+                    for (int i = 0; i < kB; ++i) {
+                        const int g = fr0 + l5 + 32 * (kB * b + i);
+                        pi[i] = buf_load_pair<TIn>(rin, valid && g >= 0 ? (unsigned)((g * a.C + c0) * (int)sizeof(TIn)) : kOut32);
+                        ph[i] = buf_load_pair<double>(rh, valid && g < 0 && g >= -a.H ? (unsigned)(((g + a.H) * a.C + c0) * (int)sizeof(double)) : kOut32);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kB; ++i) {
+                        const int g = fr0 + l5 + 32 * (kB * b + i);
+                        PH_NAT(kB * b + i) = g >= 0 ? cd{(double)pi[i].x, (double)pi[i].y} : cd{ph[i].x, ph[i].y};
+                    }
                 }
             }
             // (no stamp between the window and its transform: one there costs the build its registers)
@@ -581,11 +612,15 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
         d.P = I.P;
         const int64_t series = (int64_t)lines * a.pairs;
         const int64_t waves = (int64_t)kWaves32 * I.cus;
-        // tiles per run: enough runs for every half-wave, long enough to amortise the P - 1 warm-up
-        // transforms, a multiple of P (both halves of a wave then use the same ring slot)
+        // tiles per run: enough runs for every half-wave of the chip, a multiple of P (both halves of a
+        // wave then use the same ring slot).  A run opens with P - 1 warm-up transforms, but a wave is
+        // bound by its own chain of round trips: as long as there are idle waves, shorter runs on more
+        // of them finish sooner (512 Lines of 8 tiles, 1024 taps: runs of 2 tiles on 1024 waves against
+        // runs of 8 on 256).  PIPE_HIP_FIR_RUN_FLOOR=n restores a floor of n P tiles (A/B).
         int64_t R = ((int64_t)a.tiles_per_line * series + 2 * waves - 1) / (2 * waves);
-        if (R < 4 * (int64_t)d.P)
-            R = 4 * (int64_t)d.P;
+        static const int run_floor = std::getenv("PIPE_HIP_FIR_RUN_FLOOR") ? std::atoi(std::getenv("PIPE_HIP_FIR_RUN_FLOOR")) : 1;
+        if (R < run_floor * (int64_t)d.P)
+            R = run_floor * (int64_t)d.P;
         R = (R + d.P - 1) / d.P * d.P;
         d.R = (int)R;
         d.upl = (int)((a.tiles_per_line + 2 * R - 1) / (2 * R));
