@@ -1,7 +1,11 @@
 #!/bin/bash
 # On the GPU box: everything profiles/ holds for a round, in one call.
 #   scripts/gpu_collect_round.sh r03
-# (builds the instrumented / ablation libraries first if they are missing; they are never shipped)
+# Instrumented / ablation libraries are used when present (never shipped); build them first with
+#   scripts/build_prof_lib.sh
+#   scripts/build_ablate_lib.sh fir_ols32 PH_OLS_ABLATE ols 1 2 3
+#   scripts/build_ablate_lib.sh resampler PH_RS_PROF rsprof_ 1 && mv pipe_amd/lib/libpipe_hip_rsprof_1.so pipe_amd/lib/libpipe_hip_rsprof.so
+#   scripts/build_ablate_lib.sh fir_ols32p PH_OLSD_PROF dprof_ 1 && mv pipe_amd/lib/libpipe_hip_dprof_1.so pipe_amd/lib/libpipe_hip_dprof.so
 set -u
 TAG=${1:-r03}
 OUT=gpurun_out/$TAG
@@ -21,11 +25,22 @@ fi
 if [ -f pipe_amd/lib/libpipe_hip_rsprof.so ]; then
   PIPE_HIP_LIB=$PWD/pipe_amd/lib/libpipe_hip_rsprof.so python scripts/resampler_probe.py 40 > $OUT/resampler_phase_profile.txt 2>&1
 fi
+if [ -f pipe_amd/lib/libpipe_hip_dprof.so ]; then
+  PROF_LIB=$PWD/pipe_amd/lib/libpipe_hip_dprof.so bash scripts/gpu_long_fir.sh > $OUT/long_fir_phase_profile.txt 2>&1
+fi
+python scripts/resampler_lines_probe.py > $OUT/resampler_lines.txt 2>&1
 python scripts/resampler_probe.py 3000 > $OUT/resampler_probe.txt 2>&1
 PIPE_HIP_RESAMPLE_NO_PAIR=1 python scripts/resampler_probe.py 3000 >> $OUT/resampler_probe.txt 2>&1
 python scripts/chain_probe.py > $OUT/chain_probe.txt 2>&1
 PROBE_SECTIONS=2 python scripts/chain_probe.py >> $OUT/chain_probe.txt 2>&1
 PROBE_SECTIONS=2 PIPE_HIP_CHAIN_ONE_SECTION=1 python scripts/chain_probe.py >> $OUT/chain_probe.txt 2>&1
+rm -f $OUT/long_fir.jsonl $OUT/long_fir_short_lines.jsonl
+for n in 1024 2048 4096; do  # the same long FIRs over 512 Lines of one 4096-frame buffer
+  python bench.py --config 2 --lines 512 --buffers 1 --taps $n --no-secondary --no-cpu-baseline --no-live-pmc --steps 50 --warmup 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(json.dumps({'taps': $n, 'lines': 512, 'frames_per_line': 4096, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg_kernel_ms'], 'gsamples_per_s': round(d['value']/1e3,1)}))" >> $OUT/long_fir_short_lines.jsonl
+done
 for n in 512 1024 2048 4096; do
   python bench.py --taps $n --no-secondary --no-cpu-baseline --no-live-pmc --steps 20 --warmup 3 --buffers 32768 2>/dev/null | python -c "
 import json,sys
