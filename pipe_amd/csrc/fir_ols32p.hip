@@ -618,7 +618,8 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
         // of them finish sooner (512 Lines of 8 tiles, 1024 taps: runs of 2 tiles on 1024 waves against
         // runs of 8 on 256).  PIPE_HIP_FIR_RUN_FLOOR=n restores a floor of n P tiles (A/B).
         int64_t R = ((int64_t)a.tiles_per_line * series + 2 * waves - 1) / (2 * waves);
-        static const int run_floor = std::getenv("PIPE_HIP_FIR_RUN_FLOOR") ? std::atoi(std::getenv("PIPE_HIP_FIR_RUN_FLOOR")) : 1;
+        const char *rf = std::getenv("PIPE_HIP_FIR_RUN_FLOOR");
+        const int run_floor = rf && std::atoi(rf) > 0 ? std::atoi(rf) : 1;
         if (R < run_floor * (int64_t)d.P)
             R = run_floor * (int64_t)d.P;
         R = (R + d.P - 1) / d.P * d.P;

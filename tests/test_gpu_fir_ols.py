@@ -302,11 +302,16 @@ def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
         assert ulp_diff_f32(got[l], want, floor).max() <= 1.0, f"overlap-save form, line {l}"
 
 
-def test_partitioned_delay_line_many_short_lines_three_calls(monkeypatch):
-    """The delay line's runs on many short Lines (a run longer than a Line's tiles, halves without a
-    run, Lines ending inside a tile) over three calls of different lengths: every Line against the oracle."""
+@pytest.mark.parametrize("ntaps,run_floor", [(1100, None), (2100, None), (1100, "4")])
+def test_partitioned_delay_line_many_short_lines_three_calls(ntaps, run_floor, monkeypatch):
+    """The delay line's runs on many short Lines (runs as short as P tiles -- what fills the chip -- or,
+    with the older floor of 4 P, longer than a Line's tiles; halves without a run; Lines ending inside a
+    tile; every run opening with P - 1 warm-up windows out of the history) over three calls of different
+    lengths: every Line against the oracle."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
-    lines, C, ntaps, F = 37, 4, 1100, 700
+    if run_floor:
+        monkeypatch.setenv("PIPE_HIP_FIR_RUN_FLOOR", run_floor)
+    lines, C, F = 37, 4, 700
     taps = synth.fir_lowpass_taps(ntaps, fc=0.07, f32_rounded=True)
     calls = [3 * F, F, 5 * F - 13]
     total = sum(calls)
