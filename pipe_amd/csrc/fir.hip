@@ -31,6 +31,7 @@
 
 #include "common.hpp"
 #include "fir_hist.hpp"
+#include "fir_mfma.hpp"
 #include "fir_ols.hpp"
 
 namespace pipehip {
@@ -584,11 +585,19 @@ public:
                              nl, s, &last_kernel, &timer));
             return flip_history(s);
         }
+        const double *taps = static_cast<const double *>(taps_[cur_taps_].p);
+        // the ordered-fma form: large calls on the float64 matrix pipe (fir_mfma.hip: the same chain
+        // of fused multiply-adds, 1024 of them per instruction), the rest on the VALU
+        if (fir_mfma_takes(N_, frames, cfg.channels, nl, cus_)) {
+            hipEvent_t *done = windowed() ? nullptr : &completion;
+            PH_TRY(run_fir_mfma(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, taps, N_, frames, cfg.channels, nl,
+                                cus_, s, &last_kernel, &timer, done));
+            return flip_history(s);
+        }
         Geometry g;
         if (!choose(frames, &g))
             return PIPE_HIP_EINVAL;
         FirArgs a{};
-        const double *taps = static_cast<const double *>(taps_[cur_taps_].p);
         a.frames = frames;
         a.line_stride = frames * cfg.channels;
         a.C = cfg.channels;
