@@ -110,21 +110,22 @@ __device__ __forceinline__ void mfma_tiles(const MfmaArgs &a, const double *hp, 
         if (g < a.groups16)
             run4(ha, xa, ya);
         // D lane (q, j), register r: row 4 r + q, column j -> output 256 t + 16 j + 4 r + q
+        const int o0 = 256 * t + 16 * j + q;
+        TOut *dst = out + (f0 + o0) * a.C;
+        const int step = 4 * a.C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int o = 256 * t + 16 * j + 4 * r + q;
-            if (o < left) {
-                TOut *dst = out + (f0 + o) * a.C;
+            if (o0 + 4 * r < left) {
                 if (CG == 2)
-                    store_pair<TOut>(dst, acc0[r], acc1[r]);
+                    store_pair<TOut>(dst + r * step, acc0[r], acc1[r]);
                 else
-                    dst[0] = (TOut)acc0[r];
+                    dst[r * step] = (TOut)acc0[r];
             }
         }
     }
 }
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, int PF>
 __global__ void __launch_bounds__(kMfmaThreads)
 fir_mfma_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
                 const double *__restrict__ taps, const MfmaArgs a)
@@ -147,7 +148,7 @@ fir_mfma_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, co
     // Passes whose window lies inside the Line (no history, no end of stream) and fits kPF elements per
     // thread are requested a pass ahead: their loads fly under the previous pass's matrix instructions.
     // The others (a Line's first and last pass, filters with long windows) are staged when their turn comes.
-    constexpr int kPF = 20;
+    constexpr int kPF = PF;  // (20 covers 512 taps at 2048 frames a pass; 36, float32 input only, every filter this file takes)
     TIn pf[kPF];
     struct Pass {
         int line, c0, cg;
@@ -300,6 +301,9 @@ int run_fir_mfma(const void *d_in, int in_dtype, void *d_out, int out_dtype, con
     a.TF = 2048;
     if (((frames + 2047) / 2048) * lines * a.ngroups < 2 * (int64_t)cus)
         a.TF = 1024;
+    if (const char *e = std::getenv("PIPE_HIP_FIR_MFMA_TF"))  // A/B: 1024 / 2048 / 4096
+        if (std::atoi(e) >= 256 && std::atoi(e) % 256 == 0)
+            a.TF = std::atoi(e);
     a.tiles_per_line = (int)((frames + a.TF - 1) / a.TF);
     a.npass = (int64_t)a.tiles_per_line * lines * a.ngroups;
     const int wraw = a.TF + ntaps - 1 + a.delta + 16;
@@ -318,7 +322,9 @@ int run_fir_mfma(const void *d_in, int in_dtype, void *d_out, int out_dtype, con
     }
 #define PH_MFMA_LAUNCH(TI, TO, NAME)                                                                               \
     do {                                                                                                           \
-        auto kfn = fir_mfma_kernel<TI, TO>;                                                                        \
+        auto kfn = fir_mfma_kernel<TI, TO, 20>;                                                                    \
+        if (sizeof(TI) == 4 && (a.TF + ntaps - 1) * 2 > 20 * kMfmaThreads)                                         \
+            kfn = fir_mfma_kernel<TI, TO, (sizeof(TI) == 4 ? 36 : 20)>;                                            \
         if (lds > 64 * 1024)                                                                                       \
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)lds));                                                                 \

@@ -76,7 +76,7 @@ def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, form
     got, name = run_batch(taps, x, F, K, lines, exact=False)
     assert "partitioned" in name, name
     ref, name2 = run_batch(taps, x, F, K, lines, exact=True)
-    assert "fir_direct_kernel" in name2
+    assert "fir_direct_kernel" in name2 or "fir_mfma_kernel" in name2  # (the ordered-fma form: VALU or matrix pipe, by size)
     floor = 2.0 ** -24 * np.abs(taps).sum() * 1.0
     for l in range(lines):
         want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(K * F, channels)
@@ -96,7 +96,7 @@ def test_ols_within_one_ulp_of_oracle_and_of_direct_form(channels, ntaps, monkey
     got, name = run_batch(taps, x, F, K, lines, exact=False)
     assert "fir_ols_kernel" in name
     ref, name2 = run_batch(taps, x, F, K, lines, exact=True)
-    assert "fir_direct_kernel" in name2
+    assert "fir_direct_kernel" in name2 or "fir_mfma_kernel" in name2  # (the ordered-fma form: VALU or matrix pipe, by size)
     floor = 2.0 ** -24 * np.abs(taps).sum() * 1.0
     for l in range(lines):
         want = O.Fir(taps, channels).process(x[l].astype(np.float64)).reshape(K * F, channels)
@@ -185,7 +185,7 @@ def test_ols_full_bench_size_against_bit_exact_form(K):
         p.set_exact(True)
         p.process_batch(d_in, y_ref, K * F)
         torch.cuda.synchronize()
-        assert "fir_direct_kernel" in p.kernel_name()
+        assert "fir_mfma_kernel" in p.kernel_name() or "fir_direct_kernel" in p.kernel_name()  # the ordered-fma form
     floor = float(np.float32(2.0 ** -24 * np.abs(taps).sum()))
     differ = y_ols != y_ref
     n_diff = int(differ.sum().item())
@@ -245,7 +245,7 @@ def test_large_f32_chain_uses_ols_and_folded_gain_within_one_ulp(monkeypatch):
             torch.cuda.synchronize()
             got = d_out.cpu().numpy()
             name = p.kernel_name()
-        assert ("fir_direct" in name) if exact else ("chain_fused" in name or "fir_ols" in name)
+        assert ("fir_direct" in name or "fir_mfma" in name) if exact else ("chain_fused" in name or "fir_ols" in name)
         for l in (0, 7, 23):
             want = O.gain(O.Biquad(q, C).process(O.Fir(taps, C).process(x[l].astype(np.float64))), g).reshape(F, C)
             if exact:
@@ -289,7 +289,7 @@ def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
             outs[exact] = (torch.cat(ys, dim=1).cpu().numpy(), p.kernel_name())
     got, name = outs[False]
     ref, name2 = outs[True]
-    assert "fir_ols_kernel" in name and "fir_direct_kernel" in name2
+    assert "fir_ols_kernel" in name and ("fir_direct_kernel" in name2 or "fir_mfma_kernel" in name2)
     assert not np.isnan(got).any()
     floor = 2.0 ** -24 * np.abs(taps).sum()
     d = ulp_diff_f32(got, ref.astype(np.float64), floor)

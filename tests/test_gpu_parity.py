@@ -160,7 +160,7 @@ def test_fir_batch_equals_buffer_by_buffer(dtype):
             torch.cuda.synchronize()
             outs.append(d_out.cpu().numpy())
         got = np.concatenate(outs, axis=1)
-        assert "fir_direct_kernel" in p.kernel_name()
+        assert "fir_direct_kernel" in p.kernel_name() or "fir_mfma_kernel" in p.kernel_name()
     for l in range(L_):
         ref = O.Fir(h, C)
         want = np.concatenate([expect(ref.process(x[l, k * F:(k + 1) * F].astype(np.float64)).reshape(F, C), dtype)
