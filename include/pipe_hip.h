@@ -93,8 +93,10 @@ typedef struct pipe_hip_config {
 /* ---- allocators: the body of a ProcessorAllocatorFunc (line.go:26-30) ------ */
 /* y = x * gain */
 int pipe_hip_gain_create(const pipe_hip_config *cfg, double gain, pipe_hip_processor **out);
-/* FIR, same taps for every channel; 1 <= ntaps <= 4096 (ordered direct form; large float32
- * batches take the overlap-save form, above 512 taps partitioned: PIPE_HIP_PARAM_EXACT) */
+/* FIR, same taps for every channel; 1 <= ntaps <= 4096 (ordered direct form -- on the float64
+ * matrix pipe for large calls, whose instruction adds its products in exactly that order: the
+ * same bits; large float32 batches take the overlap-save form, above 512 taps partitioned:
+ * PIPE_HIP_PARAM_EXACT) */
 int pipe_hip_fir_create(const pipe_hip_config *cfg, const double *taps, int32_t ntaps,
                         pipe_hip_processor **out);
 /* DF2T biquad cascade; coeffs = nsections x {b0,b1,b2,a1,a2}; 1 <= nsections <= 8 */
