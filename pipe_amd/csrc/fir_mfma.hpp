@@ -8,7 +8,7 @@ namespace pipehip {
 
 class KernelTimer;
 
-constexpr int kFirMfmaMaxTaps = 2048;
+constexpr int kFirMfmaMaxTaps = 4096;
 
 // whether a call of this size goes to the matrix-pipe kernel (else fir.hip's VALU kernels)
 bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus);

@@ -1,5 +1,5 @@
 """Soak test of the ordered-fma FIR on the float64 matrix pipe (pipe_amd/csrc/fir_mfma.hip): random tap counts
-(16 .. 2048), channel counts (odd ones too), Line counts, dtypes, call sequences (calls shorter than the
+(16 .. 4096), channel counts (odd ones too), Line counts, dtypes, call sequences (calls shorter than the
 filter, ragged ends), now and then an Inf / NaN in the stream; every Line against the oracle, bit for bit.
 scripts/stress_fir_mfma.py [iterations] [seed]"""
 import os
@@ -20,7 +20,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 nonfinite_cases = 0
 for it in range(iters):
-    ntaps = int(rng.choice([16, 17, 31, 64, 255, 256, 257, 500, 1024, 2048, int(rng.integers(16, 2049))]))
+    ntaps = int(rng.choice([16, 17, 31, 64, 255, 256, 257, 500, 1024, 2048, 4096, int(rng.integers(16, 4097))]))
     C = int(rng.choice([1, 2, 2, 3, 4, 5, 8]))
     lines = int(rng.choice([1, 2, 3, 9]))
     dtype = np.float32 if rng.random() < 0.6 else np.float64

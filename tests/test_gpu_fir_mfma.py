@@ -55,7 +55,7 @@ def oracle_lines(taps, x, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("channels,ntaps", [(2, 256), (1, 16), (3, 17), (2, 255), (2, 257), (8, 64), (5, 300), (2, 1024), (2, 2048)])
+@pytest.mark.parametrize("channels,ntaps", [(2, 256), (1, 16), (3, 17), (2, 255), (2, 257), (8, 64), (5, 300), (2, 1024), (2, 2048), (2, 4096), (3, 3000)])
 def test_mfma_fir_bit_exact_over_several_calls(dtype, channels, ntaps, monkeypatch):
     lines = 3
     calls = [2500, 1024, 4096, 37]
