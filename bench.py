@@ -258,13 +258,18 @@ def main():
     # then share devices, so its numbers mean nothing): it exercises the rank / barrier / reduce
     # logic of this file end to end.
     backend = os.environ.get("PIPE_BENCH_DIST_BACKEND", "nccl")
-    if backend != "nccl":
+    if backend != "nccl" or os.environ.get("PIPE_BENCH_SHARE_DEVICES"):
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = shard.init(backend, rank, world, device=torch.device("cuda", local) if backend == "nccl" else None)
     sync = shard.ProcessSync(dist, "cuda" if backend == "nccl" else "cpu")
+    sync.settle()
+    if sync.fallback and rank == 0:
+        print(f"warning: RCCL collective failed ({sync.fallback}); barriers and reductions over gloo", file=sys.stderr)
     launch = os.environ.get("PIPE_BENCH_LAUNCH", "launcher ranks (RANK/WORLD_SIZE from the environment)"
                             if world > 1 else "single process")
+    if sync.fallback:
+        launch += " -- RCCL's first all-reduce failed, barriers and reductions over gloo"
     result = run_rank(args, rank, world, local, sync, launch)
     if rank == 0:
         print(json.dumps(result))

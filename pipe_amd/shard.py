@@ -43,8 +43,11 @@ def init(backend: str, rank: int, world: int, device=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     kw = {}
-    if device is not None:
-        kw["device_id"] = device
+    if backend == "nccl":
+        # RCCL for device tensors, gloo for host tensors: ProcessSync.settle() falls back to the
+        # latter if the first RCCL collective fails (the data path has no collective to lose)
+        # (no device_id: RCCL's communicator is then made by the first device collective, inside settle()'s try)
+        backend = "cpu:gloo,cuda:nccl"
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return dist
 
@@ -78,8 +81,33 @@ class ProcessSync:
 
     def __init__(self, dist, device: Optional[str] = None):
         self.dist, self.device = dist, device
+        self.fallback = None  # why the host-tensor path was taken, if it was
+
+    def settle(self) -> None:
+        """One RCCL all-reduce on a device tensor; if ANY rank fails it, every rank moves its barriers and
+        reductions to host tensors (gloo) -- agreed through a gloo reduction, so nobody is left waiting."""
+        if self.dist is None or self.device in (None, "cpu"):
+            return
+        import torch
+        ok, why = 1.0, ""
+        try:
+            t = torch.ones(1, dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t)
+            torch.cuda.synchronize()
+            ok = 1.0 if float(t.item()) == float(self.dist.get_world_size()) else 0.0
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raised, the bench must still report
+            ok, why = 0.0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.float64)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            self.device = "cpu"
+            self.fallback = why or "another rank's RCCL all-reduce failed"
 
     def barrier(self) -> None:
+        if self.dist is not None and self.device == "cpu":
+            import torch
+            self.dist.all_reduce(torch.zeros(1))  # (a barrier on the host-tensor backend)
+            return
         barrier(self.dist)
 
     def max(self, value: float) -> float:

@@ -122,3 +122,35 @@ def test_thread_ranks_abort_releases_the_others():
     root.abort()
     t.join(timeout=10)
     assert seen == ["released"]
+
+
+def test_process_sync_falls_back_to_host_tensors_when_the_device_collective_fails():
+    """bench.py's ranks try ONE RCCL all-reduce; if it fails anywhere, every rank agrees (through gloo) to run
+    its barriers and reductions on host tensors.  Here: no GPU, so the device tensor cannot even be made."""
+    import torch
+    from pipe_amd import shard
+
+    class FakeDist:
+        class ReduceOp:
+            MIN, MAX, SUM = "min", "max", "sum"
+        calls = []
+
+        def all_reduce(self, t, op=None):
+            assert t.device.type == "cpu"
+            self.calls.append(op)
+
+        def get_world_size(self):
+            return 2
+
+        def barrier(self):
+            raise AssertionError("the device barrier must not be used after the fallback")
+
+    if torch.cuda.is_available():
+        return
+    d = FakeDist()
+    s = shard.ProcessSync(d, "cuda")
+    s.settle()
+    assert s.device == "cpu" and s.fallback
+    s.barrier()
+    assert s.max(3.0) == 3.0
+    assert d.calls[0] == "min" and len(d.calls) == 3
