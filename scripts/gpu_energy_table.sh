@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: shader clock, socket power and kernel time at steady state for the headline kernel, its
-# ablation builds (scripts/build_ablate_lib.sh fir_ols32 PH_OLS_ABLATE ols 1 2 3), the direct form, the gain
+# ablation builds (scripts/build_ablate_lib.sh fir_ols32 PH_OLS_ABLATE ols 1 2 3), the direct form on the VALU and on the matrix pipe, the gain
 # kernel, the fused chain and the resampler.  Output: gpurun_out/energy/*.json + table.txt
 set -u
 OUT=$PWD/gpurun_out/energy
@@ -15,7 +15,8 @@ run() { # tag kind [lib]
 run idle idle
 run ols ols
 for n in 1 2 3; do [ -f pipe_amd/lib/libpipe_hip_ols$n.so ] && run ols_ablate$n ols $PWD/pipe_amd/lib/libpipe_hip_ols$n.so; done
-run direct direct
+PIPE_HIP_FIR_NO_MFMA=1 run direct direct   # the ordered-fma form on the VALU
+run mfma direct                            # ... and on the float64 matrix pipe (what large calls take)
 run gain gain
 run chain chain
 run resampler resampler
@@ -25,7 +26,7 @@ import glob, json, os, sys
 out = sys.argv[1]
 rows = []
 idle_w = None
-for tag in ["idle", "ols", "ols_ablate1", "ols_ablate2", "ols_ablate3", "direct", "gain", "chain", "resampler", "ols_again"]:
+for tag in ["idle", "ols", "ols_ablate1", "ols_ablate2", "ols_ablate3", "direct", "mfma", "gain", "chain", "resampler", "ols_again"]:
     cp, rp = os.path.join(out, f"clock_{tag}.json"), os.path.join(out, f"run_{tag}.log")
     if not os.path.exists(cp):
         continue
