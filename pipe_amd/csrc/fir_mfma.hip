@@ -273,12 +273,14 @@ bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus)
         return false;
     if (ntaps < 16 || ntaps > kFirMfmaMaxTaps || frames <= 0)
         return false;
-    // enough passes of 1024 frames x 2 channels to give every CU one; smaller calls are latency-bound
-    // (fir.hip's small-call kernel)
+    // from 32 passes of 1024 frames x 2 channels (8 pipe buffers of 4096 x 2); below that a call is bound
+    // by its launch and staging latencies and fir.hip's small-call kernel is as fast (scripts/fir_exact_sweep.py:
+    // equal up to 8 buffers, 9.3 - 10.2 us against 12 - 13 from 16 to 64)
+    (void)cus;
     const int64_t groups = (channels + 1) / 2;
     const int64_t passes = ((frames + 1023) / 1024) * lines * groups;
     const char *force = std::getenv("PIPE_HIP_FIR_MFMA_MIN_PASSES");  // (tests: 1 sends small calls here too)
-    return passes >= (force ? std::atoll(force) : (int64_t)cus);
+    return passes >= (force ? std::atoll(force) : 32);
 }
 
 int run_fir_mfma(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, double *hist_new,
