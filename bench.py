@@ -548,7 +548,8 @@ def run_rank(args, rank, world, local, sync, launch):
             nm = got[0] * C
             with P.Mix(2, F, C, dtype=np_dtype, device=local, max_batch=cap5 // F + 1) as mx:
                 mx.start()
-                other = d_in[nm:2 * nm] if d_in.numel() >= 2 * nm else own_input(nm, 1)
+                off = (nm + 63) // 64 * 64  # (a 256-byte aligned second input: an odd element offset would put the mix on its 4-byte path)
+                other = d_in[off:off + nm] if d_in.numel() >= off + nm else own_input(nm, 1)
                 mo = torch.empty(nm, dtype=t_dtype, device=dev)
                 a5 = do[:nm]
 
