@@ -7,6 +7,8 @@
 // workgroups with a grid-stride loop.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
@@ -24,6 +26,14 @@ constexpr int kMaxBlocks = 0x7FFFFFFF;
 
 template <typename T, int V>
 struct alignas(sizeof(T) * V) Pack {
+    T v[V];
+};
+
+// the same for pointers aligned to their element only (a view at an odd element offset): gfx950 loads and stores
+// 16 bytes from any 4-byte address, so such streams keep the vector path (a straddled cache line costs less
+// than four times the instructions: mix of the configs[4] size 0.0229 -> 0.0165 ms)
+template <typename T, int V>
+struct __attribute__((packed, aligned(alignof(T)))) PackU {
     T v[V];
 };
 
@@ -51,13 +61,25 @@ __global__ void __launch_bounds__(kThreads) gain_kernel(const TIn *__restrict__ 
                                                         TOut *__restrict__ out, int64_t n, double g,
                                                         int vec_ok)
 {
-    const int64_t nvec = vec_ok ? n / kPer : 0;
+    const int64_t nvec = n / kPer;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
+    if (!vec_ok) {  // pointers aligned to their element only: 16-byte accesses from 4- / 8-byte addresses (PackU)
+        using UI = PackU<TIn, kPer>;
+        using UO = PackU<TOut, kPer>;
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+            const UI x = reinterpret_cast<const UI *>(in)[i];
+            UO y;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                y.v[k] = (TOut)((double)x.v[k] * g);
+            reinterpret_cast<UO *>(out)[i] = y;
+        }
+    }
     using PI = Pack<TIn, kPer>;
     using PO = Pack<TOut, kPer>;
     const PI *vin = reinterpret_cast<const PI *>(in);
     PO *vout = reinterpret_cast<PO *>(out);
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; vec_ok && i < nvec; i += stride) {
         const PI x = vec_ok > 1 ? nt_load4<PI, TIn>(vin + i) : vin[i];
         PO y;
 #pragma unroll
@@ -77,13 +99,13 @@ struct MixPtrs {
     const void *p[8];
 };
 
-template <typename T>
+template <typename T, bool ALIGNED>
 __global__ void __launch_bounds__(kThreads) mix_kernel(const MixPtrs ins, int n_inputs,
-                                                       T *__restrict__ out, int64_t n, int vec_ok)
+                                                       T *__restrict__ out, int64_t n)
 {
-    const int64_t nvec = vec_ok ? n / kPer : 0;
+    const int64_t nvec = n / kPer;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
-    using P = Pack<T, kPer>;
+    using P = typename std::conditional<ALIGNED, Pack<T, kPer>, PackU<T, kPer>>::type;
     P *vout = reinterpret_cast<P *>(out);
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
         double acc[kPer];
@@ -170,7 +192,7 @@ public:
                                           : (int64_t)384 << 20;
         if (vec_ok && n * (int64_t)(dtype_size(in_dtype) + dtype_size(out_dtype)) >= nt_min)
             vec_ok = 2;
-        const dim3 grid(grid_for(vec_ok ? n / kPer : n));
+        const dim3 grid(grid_for(n / kPer > 0 ? n / kPer : n));
         PH_TRY(timer.begin(s));
         // a ProcessFunc-form buffer: this launch is the call's last operation and signals its completion
         hipEvent_t done = completion;
@@ -220,16 +242,20 @@ public:
             ptrs.p[i] = d_ins[i];
             vec_ok = vec_ok && aligned_to(d_ins[i], dtype_size(cfg.dtype) * kPer);
         }
-        const dim3 grid(grid_for(vec_ok ? n / kPer : n));
+        const dim3 grid(grid_for(n / kPer > 0 ? n / kPer : n));
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         PH_TRY(timer.pair(&ev_a, &ev_b));
         if (cfg.dtype == PIPE_HIP_F32) {
-            hipExtLaunchKernelGGL(mix_kernel<float>, grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs,
-                               (float *)d_out, n, vec_ok);
+            if (vec_ok)
+                hipExtLaunchKernelGGL((mix_kernel<float, true>), grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs, (float *)d_out, n);
+            else
+                hipExtLaunchKernelGGL((mix_kernel<float, false>), grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs, (float *)d_out, n);
             last_kernel = "mix_kernel<f32>";
         } else {
-            hipExtLaunchKernelGGL(mix_kernel<double>, grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs,
-                               (double *)d_out, n, vec_ok);
+            if (vec_ok)
+                hipExtLaunchKernelGGL((mix_kernel<double, true>), grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs, (double *)d_out, n);
+            else
+                hipExtLaunchKernelGGL((mix_kernel<double, false>), grid, dim3(kThreads), 0, s, ev_a, ev_b, 0, ptrs, n_inputs, (double *)d_out, n);
             last_kernel = "mix_kernel<f64>";
         }
         PH_HIP(hipGetLastError());
