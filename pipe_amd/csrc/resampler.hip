@@ -436,8 +436,13 @@ template <typename T>
 struct PairRaw;  // one 16-byte (float32: two frames) / 32-byte (float64: two frames) piece of the window
 template <>
 struct PairRaw<float> {
-    float4 v;
-    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const float4 *>(p); }
+    // (element-aligned: gfx950 loads 16 bytes from any 4-byte address, so a stream that starts at an odd
+    // frame of its buffer keeps this kernel)
+    struct __attribute__((packed, aligned(4))) U4 {
+        float x, y, z, w;
+    };
+    U4 v;
+    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const U4 *>(p); }
     __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
     {
         c0[0] = (double)v.x;
@@ -448,11 +453,14 @@ struct PairRaw<float> {
 };
 template <>
 struct PairRaw<double> {
-    double2 a, b;
+    struct __attribute__((packed, aligned(8))) U2 {
+        double x, y;
+    };
+    U2 a, b;
     __device__ __forceinline__ void load(const double *p)
     {
-        a = *reinterpret_cast<const double2 *>(p);
-        b = *reinterpret_cast<const double2 *>(p + 2);
+        a = *reinterpret_cast<const U2 *>(p);
+        b = *reinterpret_cast<const U2 *>(p + 2);
     }
     __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
     {
@@ -992,9 +1000,7 @@ private:
         }
         const int threads = (ql + 63) / 64 * 64;
         const size_t es_in = dtype_size(in_dtype);
-        const bool vec_ok = reinterpret_cast<uintptr_t>(a.in) % 16 == 0 &&
-                            (cfg.lines == 1 || ((size_t)a.in_frames * 2 * es_in) % 16 == 0);
-        if (!vec_ok)
+        if (reinterpret_cast<uintptr_t>(a.in) % es_in != 0)
             return false;
         if (!ensure_pair_taps(ql, dmin))
             return false;
