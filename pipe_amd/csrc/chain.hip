@@ -154,7 +154,7 @@ private:
             if (!gain_value(stages[2].get(), &g))
                 return false;
         }
-        return reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+        return reinterpret_cast<uintptr_t>(d_in) % 8 == 0 && reinterpret_cast<uintptr_t>(d_out) % 8 == 0;  // (float32 channel pairs)
     }
 
     DevBuf tmp_[2];

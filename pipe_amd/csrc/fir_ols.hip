@@ -589,7 +589,8 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
               int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {
     if (impl_->P > 1) {
-        if (channels % 2 != 0 || reinterpret_cast<uintptr_t>(d_in) % 16 != 0 || reinterpret_cast<uintptr_t>(d_out) % 16 != 0)
+        if (channels % 2 != 0 || reinterpret_cast<uintptr_t>(d_in) % (2 * dtype_size(in_dtype)) != 0 ||
+            reinterpret_cast<uintptr_t>(d_out) % (2 * dtype_size(out_dtype)) != 0)
             return PIPE_HIP_EINVAL;  // (the caller asked partitioned_ok() first)
         return run_ols32p(*impl_, d_in, in_dtype, d_out, out_dtype, hist, hist_new, frames, channels, lines, s, kernel_name,
                           timer);
@@ -606,9 +607,11 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
     a.nitems = (int64_t)a.tiles_per_line * a.pairs * lines;
-    // pairs are naturally aligned when the channel count is even and the buffers are
-    const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 &&
-                     reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    // channel pairs are accessed as one 8- / 16-byte piece (buffer loads and stores: any pair-aligned address
+    // will do, e.g. a stream that starts at an odd frame of its buffer)
+    const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % (2 * dtype_size(in_dtype)) == 0 &&
+                     reinterpret_cast<uintptr_t>(d_out) % (2 * dtype_size(out_dtype)) == 0;
+    const bool vec16 = vec && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
     // the 32 x 32 decomposition (one transform per half-wave, fir_ols32.hip): even channel counts
     // (default; PIPE_HIP_OLS_VARIANT=16 selects the 16 x 16 x 4 kernel of this file for A/B runs)
     static const int variant = std::getenv("PIPE_HIP_OLS_VARIANT") ? std::atoi(std::getenv("PIPE_HIP_OLS_VARIANT")) : 32;
@@ -617,26 +620,26 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
                          kernel_name, timer);
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32>";
-        if (vec)
+        if (vec16)
             return launch_ols<float, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
         return launch_ols<float, float, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f64,f32>";
-        if (vec)
+        if (vec16)
             return launch_ols<double, float, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
         return launch_ols<double, float, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     // float64 output: only as an intermediate of a chain that ends in float32
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f32,f64>";
-        if (vec)
+        if (vec16)
             return launch_ols<float, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
         return launch_ols<float, double, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }
     if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
         *kernel_name = "fir_ols_kernel<f64,f64>";
-        if (vec)
+        if (vec16)
             return launch_ols<double, double, kVecWaves, true>(*impl_, d_in, d_out, hist, a, s, timer);
         return launch_ols<double, double, 8, false>(*impl_, d_in, d_out, hist, a, s, timer);
     }

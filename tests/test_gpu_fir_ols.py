@@ -335,3 +335,49 @@ def test_partitioned_delay_line_many_short_lines_three_calls(ntaps, run_floor, m
         want = O.Fir(taps, C).process(x[l].astype(np.float64)).reshape(total, C)
         d = ulp_diff_f32(got[l], want, floor)
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp at {np.unravel_index(d.argmax(), d.shape)}"
+
+
+@pytest.mark.parametrize("ntaps", [256, 1024])
+def test_streams_that_start_at_an_odd_frame_keep_the_fast_kernels(ntaps, monkeypatch):
+    """A device buffer that starts at an odd frame of its allocation is aligned to a channel pair (8 bytes of
+    float32), not to 16: the overlap-save kernels, the fused chain and the pair resampler access pairs / use
+    element-aligned 16-byte loads, so such a view takes the same kernel and gives the same bits as an aligned copy."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    C, F, K, lines = 2, 4096, 8, 3
+    taps = synth.fir_lowpass_taps(ntaps, fc=0.1, f32_rounded=True)
+    n = lines * K * F * C
+    data = torch.empty(n, dtype=torch.float32, device="cuda")
+    P.synth_fill(data, synth.line_seed(5))
+    big = torch.empty(n + 16, dtype=torch.float32, device="cuda")
+
+    def view(off):  # the same samples in a buffer that starts `off` elements into its allocation
+        v = big[off:off + n]
+        v.copy_(data)
+        return v
+    outs = {}
+    for off in (0, 2, 6):  # elements: 0, one frame, three frames
+        src = view(off)
+        dst_big = torch.full((n + 16,), float("nan"), dtype=torch.float32, device="cuda")
+        dst = dst_big[off:off + n]
+        with P.Fir(taps, F, C, dtype=np.float32, lines=lines, max_batch=K) as p:
+            p.start()
+            p.process_batch(src, dst, K * F)
+            torch.cuda.synchronize()
+            outs[off] = (dst.cpu().numpy(), p.kernel_name())
+    assert outs[0][1] == outs[2][1] == outs[6][1] and "fir_ols_kernel" in outs[0][1] and "32x32" in outs[0][1], [v[1] for v in outs.values()]
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][0], outs[6][0])
+    # the fused chain on the same views
+    q = synth.biquad_rbj_lowpass()
+    kw = dict(dtype=np.float32, lines=lines, max_batch=K)
+    res = {}
+    for off in (0, 2):
+        src = view(off)
+        dst = torch.full((n + 16,), float("nan"), dtype=torch.float32, device="cuda")[off:off + n]
+        with P.Chain([P.Fir(taps[:256], F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.5, F, C, **kw)]) as ch:
+            ch.start()
+            ch.process_batch(src, dst, K * F)
+            torch.cuda.synchronize()
+            res[off] = (dst.cpu().numpy(), ch.kernel_name())
+            ch.flush()
+    assert res[0][1] == res[2][1] and "chain_fused_kernel" in res[0][1], (res[0][1], res[2][1])
+    assert np.array_equal(res[0][0], res[2][0])
