@@ -609,9 +609,10 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     a.nitems = (int64_t)a.tiles_per_line * a.pairs * lines;
     // channel pairs are accessed as one 8- / 16-byte piece (buffer loads and stores: any pair-aligned address
     // will do, e.g. a stream that starts at an odd frame of its buffer)
-    const bool vec = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % (2 * dtype_size(in_dtype)) == 0 &&
-                     reinterpret_cast<uintptr_t>(d_out) % (2 * dtype_size(out_dtype)) == 0;
-    const bool vec16 = vec && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    // (an odd channel count: the last channel alone in its "pair", pieces then aligned to an element only)
+    const size_t pin = (channels % 2 ? 1 : 2) * dtype_size(in_dtype), pout = (channels % 2 ? 1 : 2) * dtype_size(out_dtype);
+    const bool vec = reinterpret_cast<uintptr_t>(d_in) % pin == 0 && reinterpret_cast<uintptr_t>(d_out) % pout == 0;
+    const bool vec16 = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
     // the 32 x 32 decomposition (one transform per half-wave, fir_ols32.hip): even channel counts
     // (default; PIPE_HIP_OLS_VARIANT=16 selects the 16 x 16 x 4 kernel of this file for A/B runs)
     static const int variant = std::getenv("PIPE_HIP_OLS_VARIANT") ? std::atoi(std::getenv("PIPE_HIP_OLS_VARIANT")) : 32;

@@ -86,7 +86,8 @@ int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, 
     a.H = I.N - 1;
     a.HP = a.H;
     a.L = kM - a.HP;
-    a.pairs = channels / 2;
+    a.pairs = (channels + 1) / 2;
+    a.odd = channels & 1;
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
     a.ipl = a.tiles_per_line * a.pairs;

@@ -72,6 +72,8 @@ struct Args32 {
     int stagger;          // fused chain: the second wave of every SIMD starts this many s_sleep(127) late
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
+    int odd;              // C is odd: the last "pair" is ONE channel (its imaginary part: whatever follows it in memory,
+                          // finite and unused -- real taps keep the parts apart; only its real part is stored).  S = 0 only
     void *hist_new;       // float64 elements (S = 0), the stream's float32 (fused chain, S > 0)
 };
 
@@ -1256,10 +1258,19 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 base, 0, bytes31((a.frames - t00) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
             const int o0 = (((tile - tile0) * a.L + l5 - a.HP) * a.C + c0) * (int)sizeof(TOut);
             const int i0 = valid ? l5 - a.HP : -2048;  // window index - HP of register 0: outputs need >= 0
+            const bool lone = S == 0 && a.odd && c0 + 1 == a.C;  // (uniform over a half-wave)
+            if (lone) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int off = o0 + r * (int)out_step;
-                buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+                for (int r = 0; r < 32; ++r) {
+                    const int off = o0 + r * (int)out_step;
+                    buf_store_one<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int off = o0 + r * (int)out_step;
+                    buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+                }
             }
         }
 #ifdef PH_FUSE_PROF

@@ -184,6 +184,21 @@ __device__ __forceinline__ void buf_store_pair<double>(__amdgpu_buffer_rsrc_t r,
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), r, voff, 0, 0);
 }
 
+// one element (the lone channel of an odd channel count)
+template <typename T>
+__device__ __forceinline__ void buf_store_one(__amdgpu_buffer_rsrc_t r, unsigned voff, double v);
+template <>
+__device__ __forceinline__ void buf_store_one<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, 0, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store_one<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, double v)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, 0, 0);
+}
+
 // Lanes of one wave talk through the wave-private buffer.  The hardware keeps a
 // wave's LDS operations in order, but the compiler reasons per thread and would
 // happily move a read above a write to a "different" address: fence every phase.
