@@ -33,11 +33,11 @@ constexpr int kM = kM32;
 constexpr int kHalf = kHalf32;
 constexpr int kPlane = kPlane32;
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, bool MONO = false>
 int launch32(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, Args32 a, hipStream_t s,
              KernelTimer *timer)
 {
-    auto kfn = fir_ols32_kernel<TIn, TOut, 0>;
+    auto kfn = fir_ols32_kernel<TIn, TOut, 0, false, false, MONO>;
     const size_t lds = sizeof(double2) * (kHalf + 1 + 31 * 32) + sizeof(double) * (size_t)kPlane * 2 * kWaves32;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -90,9 +90,33 @@ int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, 
     a.odd = channels & 1;
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
+    // one channel: two tiles of the Line per complex sequence (tile t and tile t + half the tiles) -- the same
+    // efficiency as a channel pair; a Line of one tile, or PIPE_HIP_OLS_MONO_ALONE (A/B), keeps the channel alone
+    const bool mono = channels == 1 && a.tiles_per_line >= 2 && !std::getenv("PIPE_HIP_OLS_MONO_ALONE");
+    if (mono) {
+        a.tiles_per_line = (a.tiles_per_line + 1) / 2;
+        a.mono_shift = (int64_t)a.tiles_per_line * a.L;
+        a.odd = 0;
+    }
     a.ipl = a.tiles_per_line * a.pairs;
     a.upl = (a.ipl + 1) / 2;
     a.nunits = (int64_t)a.upl * lines;
+    if (mono) {
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+            *kernel_name = "fir_ols_kernel<f32,f32,32x32>";
+            return launch32<float, float, true>(I, d_in, d_out, hist, a, s, timer);
+        }
+        if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
+            *kernel_name = "fir_ols_kernel<f64,f32,32x32>";
+            return launch32<double, float, true>(I, d_in, d_out, hist, a, s, timer);
+        }
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
+            *kernel_name = "fir_ols_kernel<f32,f64,32x32>";
+            return launch32<float, double, true>(I, d_in, d_out, hist, a, s, timer);
+        }
+        *kernel_name = "fir_ols_kernel<f64,f64,32x32>";
+        return launch32<double, double, true>(I, d_in, d_out, hist, a, s, timer);
+    }
     if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
         *kernel_name = "fir_ols_kernel<f32,f32,32x32>";
         return launch32<float, float>(I, d_in, d_out, hist, a, s, timer);

@@ -72,6 +72,7 @@ struct Args32 {
     int stagger;          // fused chain: the second wave of every SIMD starts this many s_sleep(127) late
     int64_t nunits;
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
+    int64_t mono_shift;   // MONO kernels (one channel): the frames between the two tiles a half-wave's complex sequence carries
     int odd;              // C is odd: the last "pair" is ONE channel (its imaginary part: whatever follows it in memory,
                           // finite and unused -- real taps keep the parts apart; only its real part is stored).  S = 0 only
     void *hist_new;       // float64 elements (S = 0), the stream's float32 (fused chain, S > 0)
@@ -1026,7 +1027,11 @@ struct HistOf<float, S> {
 
 // S = 0: the FIR alone.  S = 1, 2: the FIR's tile goes through an S-section biquad cascade and a
 // gain before it is stored (chain_fused.hip; fa / fc are then the epilogue's arguments).
-template <typename TIn, typename TOut, int S = 0, bool GENERAL = false, bool LOCAL = false>
+// MONO (S = 0, one channel): a half-wave's complex sequence carries TWO TILES of the one channel -- tile t as
+// the real part, tile t + tiles_per_line as the imaginary part, `mono_shift` frames later in the same Line --
+// instead of a channel and its neighbour: the Line is run as if it had two channels, the second being its own
+// second half.  tiles_per_line is then HALF the Line's tiles.
+template <typename TIn, typename TOut, int S = 0, bool GENERAL = false, bool LOCAL = false, bool MONO = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
 fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                  const typename HistOf<TIn, S>::type *__restrict__ hist_base,
@@ -1105,6 +1110,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const unsigned in_step = (unsigned)(32 * a.C * sizeof(TIn));    // 32 frames
     const unsigned out_step = (unsigned)(32 * a.C * sizeof(TOut));
     auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
+    [[maybe_unused]] auto bytes31c = [](int64_t n) { return (int)(n < 0 ? 0 : (n < 0x7FFFFFFF ? n : 0x7FFFFFFF)); };
 
 #ifdef PH_FUSE_PROF
     unsigned long long fprof_acc[kFuseProfPhases] = {};
@@ -1167,9 +1173,19 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 const_cast<TIn *>(base), 0, bytes31((a.frames - fr00) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
             const unsigned v0 = valid ? (unsigned)((((tile - tile0) * a.L + l5) * a.C + c0) * (int)sizeof(TIn)) : kOut32;
             In2 pf[32];
+            if constexpr (MONO) {
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(base + a.mono_shift), 0, bytes31c((a.frames - fr00 - a.mono_shift) * (int64_t)sizeof(TIn)), 0x00020000);
 #pragma unroll
-            for (int r = 0; r < 32; ++r)
-                pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+                for (int r = 0; r < 32; ++r) {
+                    pf[r].x = buf_load_one<TIn>(rs, v0 + (unsigned)r * in_step);
+                    pf[r].y = buf_load_one<TIn>(rb, v0 + (unsigned)r * in_step);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    pf[r] = buf_load_pair<TIn>(rs, v0 + (unsigned)r * in_step);
+            }
 #pragma unroll
             for (int r = 0; r < 32; ++r)
                 PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
@@ -1188,6 +1204,29 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<THist *>(hist0), 0, bytes31((int64_t)a.H * a.C * (int64_t)sizeof(THist)), 0x00020000);
             const int fr0 = tile * a.L - a.HP;  // (first tiles: small)
+            if constexpr (MONO) {
+                // the real part: history then input; the imaginary part: the Line `mono_shift` frames on (always input)
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(in0 + a.mono_shift - a.HP), 0, bytes31c((a.frames - a.mono_shift + a.HP) * (int64_t)sizeof(TIn)), 0x00020000);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    TIn pa[16], pb[16];
+                    THist pc[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int g = fr0 + l5 + 32 * (16 * b + k);
+                        pa[k] = buf_load_one<TIn>(rin, valid && g >= 0 ? (unsigned)(g * (int)sizeof(TIn)) : kOut32);
+                        pb[k] = buf_load_one<TIn>(rb, valid ? (unsigned)((g + a.HP) * (int)sizeof(TIn)) : kOut32);
+                        if (b == 0)
+                            pc[k] = buf_load_one<THist>(rh, valid && g < 0 && g >= -a.H ? (unsigned)((g + a.H) * (int)sizeof(THist)) : kOut32);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int g = fr0 + l5 + 32 * (16 * b + k);
+                        PH_NAT(16 * b + k) = cd{b == 0 && g < 0 ? (double)pc[k] : (double)pa[k], (double)pb[k]};
+                    }
+                }
+            } else {
             {
                 In2 pi[16];
                 H2 ph[16];
@@ -1213,6 +1252,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
                 for (int r = 16; r < 32; ++r)
                     PH_NAT(r) = cd{(double)pi[r - 16].x, (double)pi[r - 16].y};
+            }
             }
         }
         // the next unit's coordinates (uniform)
@@ -1259,7 +1299,16 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             const int o0 = (((tile - tile0) * a.L + l5 - a.HP) * a.C + c0) * (int)sizeof(TOut);
             const int i0 = valid ? l5 - a.HP : -2048;  // window index - HP of register 0: outputs need >= 0
             const bool lone = S == 0 && a.odd && c0 + 1 == a.C;  // (uniform over a half-wave)
-            if (lone) {
+            if constexpr (MONO) {
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                    base + a.mono_shift, 0, bytes31c((a.frames - t00 - a.mono_shift) * (int64_t)sizeof(TOut)), 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const unsigned voff = i0 + 32 * r >= 0 ? (unsigned)(o0 + r * (int)out_step) : kOut32;
+                    buf_store_one<TOut>(rs, voff, PH_NAT(r).re);
+                    buf_store_one<TOut>(rb, voff, PH_NAT(r).im);
+                }
+            } else if (lone) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int off = o0 + r * (int)out_step;

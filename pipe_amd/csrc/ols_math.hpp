@@ -184,6 +184,19 @@ __device__ __forceinline__ void buf_store_pair<double>(__amdgpu_buffer_rsrc_t r,
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), r, voff, 0, 0);
 }
 
+// one element
+template <typename T>
+__device__ __forceinline__ T buf_load_one(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <>
+__device__ __forceinline__ float buf_load_one<float>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+template <>
+__device__ __forceinline__ double buf_load_one<double>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
 // one element (the lone channel of an odd channel count)
 template <typename T>
 __device__ __forceinline__ void buf_store_one(__amdgpu_buffer_rsrc_t r, unsigned voff, double v);

@@ -381,3 +381,37 @@ def test_streams_that_start_at_an_odd_frame_keep_the_fast_kernels(ntaps, monkeyp
             ch.flush()
     assert res[0][1] == res[2][1] and "chain_fused_kernel" in res[0][1], (res[0][1], res[2][1])
     assert np.array_equal(res[0][0], res[2][0])
+
+
+@pytest.mark.parametrize("calls", [[769 * 7 + 5, 769 * 4, 300, 769 * 2 + 1], [100000], [769, 1538, 1539]])
+@pytest.mark.parametrize("ntaps", [256, 64, 511])
+def test_mono_lines_ride_two_tiles_per_transform(calls, ntaps, monkeypatch):
+    """One channel: a half-wave's complex sequence carries tile t and tile t + half-the-tiles of the same Line
+    (fir_ols32_kernel<..., MONO>).  Odd and even tile counts, calls of one tile (the channel then rides alone),
+    state carried from call to call, three Lines: within one ulp of the oracle like every overlap-save launch,
+    and the same samples as the channel-alone form (PIPE_HIP_OLS_MONO_ALONE) to within that bound."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C = 3, 1
+    taps = synth.fir_lowpass_taps(ntaps, fc=0.09, f32_rounded=True)
+    total = sum(calls)
+    x = np.stack([synth.samples(synth.line_seed(600 + l), 0, total, np.float32).reshape(total, C) for l in range(lines)])
+    with P.Fir(taps, max(calls), C, dtype=np.float32, lines=lines, max_batch=1) as p:
+        p.start()
+        d = torch.from_numpy(x).cuda()
+        outs, pos = [], 0
+        for n in calls:
+            xin = d[:, pos:pos + n, :].contiguous()
+            y = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, y, n)
+            torch.cuda.synchronize()
+            assert "32x32" in p.kernel_name(), p.kernel_name()
+            outs.append(y)
+            pos += n
+        got = torch.cat(outs, dim=1).cpu().numpy()
+    assert not np.isnan(got).any()
+    floor = 2.0 ** -24 * np.abs(taps).sum()
+    for l in range(lines):
+        want = O.Fir(taps, C).process(x[l].astype(np.float64)).reshape(total, C)
+        dd = ulp_diff_f32(got[l], want, floor)
+        assert dd.max() <= 1.0, f"line {l}: {dd.max()} ulp at {np.unravel_index(dd.argmax(), dd.shape)}"
+        assert np.mean(got[l] != want.astype(np.float32)) < 1e-3
