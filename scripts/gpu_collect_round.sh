@@ -47,6 +47,14 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print(json.dumps({'taps': $n, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg_kernel_ms'], 'gsamples_per_s': round(d['value']/1e3,1), 'bit_exact_gsamples_per_s': round(d['bit_exact_form']['msamples_per_s']/1e3,1)}))" >> $OUT/long_fir.jsonl
 done
+rm -f $OUT/channels.jsonl
+for c in 1 2 3; do  # the headline workload with one, two, three channels
+  python bench.py --channels $c --buffers 32768 --no-secondary --no-cpu-baseline --no-live-pmc --steps 10 --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(json.dumps({'channels': $c, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg_kernel_ms'], 'hbm_frac': r['frac'], 'gsamples_per_s': round(d['value']/1e3,1)}))" >> $OUT/channels.jsonl
+done
+python scripts/fir_exact_sweep.py > $OUT/fir_exact_sweep.txt 2>&1
 SEC=3 bash scripts/gpu_energy_table.sh > $OUT/energy.log 2>&1
 cp gpurun_out/energy/table.txt $OUT/energy_table.txt
 grep -v amdgpu $OUT/chain_probe.txt; cat $OUT/long_fir.jsonl; tail -4 $OUT/hostcall.jsonl; tail -12 $OUT/energy_table.txt
