@@ -580,8 +580,8 @@ public:
         // direct form (bit-exact).
         if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
             ols_->items(frames, cfg.channels, nl) >= ols_min_items() &&
-            (!ols_->partitioned() || (reinterpret_cast<uintptr_t>(d_in) % (2 * dtype_size(in_dtype)) == 0 &&
-                                       reinterpret_cast<uintptr_t>(d_out) % (2 * dtype_size(out_dtype)) == 0))) {
+            (!ols_->partitioned() || (reinterpret_cast<uintptr_t>(d_in) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(in_dtype)) == 0 &&
+                                       reinterpret_cast<uintptr_t>(d_out) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(out_dtype)) == 0))) {
             PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, frames, cfg.channels,
                              nl, s, &last_kernel, &timer));
             return flip_history(s);

@@ -421,7 +421,7 @@ bool Plan::supports(int ntaps, int channels)
     if (std::getenv("PIPE_HIP_FIR_EXACT"))
         return false;
     // up to 512 taps: one spectrum; 513 .. 4096: partitioned (even channel counts: the 32 x 32 kernel)
-    return ntaps >= 16 && (ntaps <= 512 || (ntaps <= 4096 && channels % 2 == 0 && !std::getenv("PIPE_HIP_FIR_NO_PARTITION")));
+    return ntaps >= 16 && (ntaps <= 512 || (ntaps <= 4096 && (channels % 2 == 0 || channels == 1) && !std::getenv("PIPE_HIP_FIR_NO_PARTITION")));
 }
 
 // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2 (the kernels take the upper half from
@@ -589,8 +589,9 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
               int channels, int lines, hipStream_t s, const char **kernel_name, KernelTimer *timer)
 {
     if (impl_->P > 1) {
-        if (channels % 2 != 0 || reinterpret_cast<uintptr_t>(d_in) % (2 * dtype_size(in_dtype)) != 0 ||
-            reinterpret_cast<uintptr_t>(d_out) % (2 * dtype_size(out_dtype)) != 0)
+        const size_t piece = channels == 1 ? 1 : 2;  // (a channel pair, or the one channel's elements)
+        if ((channels % 2 != 0 && channels != 1) || reinterpret_cast<uintptr_t>(d_in) % (piece * dtype_size(in_dtype)) != 0 ||
+            reinterpret_cast<uintptr_t>(d_out) % (piece * dtype_size(out_dtype)) != 0)
             return PIPE_HIP_EINVAL;  // (the caller asked partitioned_ok() first)
         return run_ols32p(*impl_, d_in, in_dtype, d_out, out_dtype, hist, hist_new, frames, channels, lines, s, kernel_name,
                           timer);

@@ -269,7 +269,10 @@ struct ArgsD {
     } while (0)
 #endif
 
-template <typename TIn, typename TOut>
+// MONO (one channel): the Line is run as if it had two channels, the second being its own second half,
+// a.mono_shift frames on (ols32_kernel.hpp: the same device in the one-spectrum kernel); a.tiles_per_line is
+// then half the Line's tiles, and every piece of window / output is two element accesses through two resources.
+template <typename TIn, typename TOut, bool MONO = false>
 __global__ void __launch_bounds__(kWaves32 * 64)
 fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const double *__restrict__ hist_base,
                   const double2 *__restrict__ tw_g, const ArgsD t)
@@ -343,6 +346,19 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                     const_cast<TIn *>(base), 0, bytes31((a.frames - fr00) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
                 unsigned v0 = valid ? (unsigned)(((half * t.R * kL + l5) * a.C + c0) * (int)sizeof(TIn)) : kOut32;
                 asm volatile("" : "+v"(v0));
+                if constexpr (MONO) {
+                    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<TIn *>(base + a.mono_shift), 0, bytes31((a.frames - fr00 - a.mono_shift) * (int64_t)sizeof(TIn)), 0x00020000);
+                    TIn pa[32], pb[32];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        pa[r] = buf_load_one<TIn>(rs, v0 + (unsigned)r * in_step);
+                        pb[r] = buf_load_one<TIn>(rb, v0 + (unsigned)r * in_step);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 32; ++r)
+                        PH_NAT(r) = cd{(double)pa[r], (double)pb[r]};
+                } else {
                 In2 pf[32];
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
@@ -356,6 +372,36 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
 #pragma unroll
                 for (int r = 0; r < 32; ++r)
                     PH_NAT(r) = cd{(double)pf[r].x, (double)pf[r].y};
+                }
+            } else if constexpr (MONO) {
+                // the window reaches back into the history: the real part at frame g, the imaginary part at frame
+                // g + mono_shift of the same Line (history below 0 for either): four requests per index, branch-free
+                const TIn *in0 = in_base + (int64_t)line * a.line_stride;
+                const double *hist0 = hist_base + (int64_t)line * a.H;
+                constexpr int kBack = 8192;  // (a window starts at most 4096 + 512 frames before its run)
+                const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(in0), 0, bytes31(a.frames * (int64_t)sizeof(TIn)), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TIn *>(in0 + a.mono_shift - kBack), 0, bytes31((a.frames - a.mono_shift + kBack) * (int64_t)sizeof(TIn)), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double *>(hist0), 0, bytes31((int64_t)a.H * (int64_t)sizeof(double)), 0x00020000);
+                const int fr0 = tile * kL - kL;
+                const int64_t sh = a.mono_shift;
+#pragma unroll 1
+                for (int b = 0; b < 32; b += 32) {  // (one trip: keeps the block's addresses out of the transform's registers)
+                    int l5w = l5;
+                    asm volatile("" : "+v"(l5w));
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const int g = fr0 + l5w + 32 * r;
+                        const int64_t g2 = g + sh;
+                        const TIn xr = buf_load_one<TIn>(rin, valid && g >= 0 ? (unsigned)(g * (int)sizeof(TIn)) : kOut32);
+                        const double hr = buf_load_one<double>(rh, valid && g < 0 && g >= -a.H ? (unsigned)((g + a.H) * 8) : kOut32);
+                        const TIn xi = buf_load_one<TIn>(rb, valid && g2 >= 0 ? (unsigned)((g + kBack) * (int)sizeof(TIn)) : kOut32);
+                        const double hi2 = buf_load_one<double>(rh, valid && g2 < 0 && g2 >= -(int64_t)a.H ? (unsigned)((int)(g2 + a.H) * 8) : kOut32);
+                        PH_NAT(r) = cd{g >= 0 ? (double)xr : hr, g2 >= 0 ? (double)xi : hi2};
+                    }
+                }
             } else if constexpr (sizeof(TIn) == 8) {
                 // the window reaches back into the history; float64 input: the plain ladder (the batched
                 // form below costs this variant, whose window alone is 128 registers, 40 bytes of scratch)
@@ -499,7 +545,15 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
                     const int off = o0 + r * (int)out_step;
                     if ((PH_OLSD_ABLATE & 1) && PH_NAT(r).re != 1234.5)
                         continue;
-                    buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+                    if constexpr (MONO) {
+                        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                            base + a.mono_shift, 0, bytes31((a.frames - t00 - a.mono_shift) * (int64_t)sizeof(TOut)), 0x00020000);
+                        const unsigned voff = i0 + 32 * r >= 0 ? (unsigned)off : kOut32;
+                        buf_store_one<TOut>(rs, voff, PH_NAT(r).re);
+                        buf_store_one<TOut>(rb, voff, PH_NAT(r).im);
+                    } else {
+                        buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+                    }
                 }
             }
             PH_D_STAMP(5);
@@ -520,11 +574,11 @@ fir_ols32d_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, 
 #endif
 }
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, bool MONO = false>
 int launch32d(const Plan::Impl &I, const void *d_in, void *d_out, const double *hist, ArgsD t, hipStream_t s,
               KernelTimer *timer)
 {
-    auto kfn = fir_ols32d_kernel<TIn, TOut>;
+    auto kfn = fir_ols32d_kernel<TIn, TOut, MONO>;
     const size_t lds = sizeof(double2) * (31 * 32 + kHalf32 + 1) + sizeof(double) * (size_t)kPlane32 * 2 * kWaves32;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -609,6 +663,12 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
         a.pairs = channels / 2;
         a.lines = lines;
         a.tiles_per_line = (int)((frames + 511) / 512);
+        const bool mono = channels == 1;
+        if (mono) {  // two tiles of the one channel per complex sequence: tile t and tile t + half the tiles
+            a.pairs = 1;
+            a.tiles_per_line = (a.tiles_per_line + 1) / 2;
+            a.mono_shift = (int64_t)a.tiles_per_line * 512;
+        }
         d.P = I.P;
         const int64_t series = (int64_t)lines * a.pairs;
         const int64_t waves = (int64_t)kWaves32 * I.cus;
@@ -631,6 +691,22 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
         if (I.scratch.bytes < need)
             PH_TRY(I.scratch.alloc(need));
         d.ring = static_cast<double2 *>(I.scratch.p);
+        if (mono) {
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+                *kernel_name = "fir_ols_kernel<f32,f32,32x32,partitioned>";
+                return launch32d<float, float, true>(I, d_in, d_out, hist, d, s, timer);
+            }
+            if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F32) {
+                *kernel_name = "fir_ols_kernel<f64,f32,32x32,partitioned>";
+                return launch32d<double, float, true>(I, d_in, d_out, hist, d, s, timer);
+            }
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F64) {
+                *kernel_name = "fir_ols_kernel<f32,f64,32x32,partitioned>";
+                return launch32d<float, double, true>(I, d_in, d_out, hist, d, s, timer);
+            }
+            *kernel_name = "fir_ols_kernel<f64,f64,32x32,partitioned>";
+            return launch32d<double, double, true>(I, d_in, d_out, hist, d, s, timer);
+        }
         if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
             *kernel_name = "fir_ols_kernel<f32,f32,32x32,partitioned>";
             return launch32d<float, float>(I, d_in, d_out, hist, d, s, timer);

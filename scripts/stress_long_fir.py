@@ -21,7 +21,7 @@ t0 = time.time()
 worst_all = 0.0
 for it in range(iters):
     ntaps = int(rng.choice([513, 600, 1000, 1024, 1025, 1536, 2048, 3000, 4096, int(rng.integers(513, 4097))]))
-    C = int(rng.choice([2, 2, 4, 6]))
+    C = int(rng.choice([1, 2, 2, 4, 6]))
     lines = int(rng.choice([1, 2, 3, 7]))
     ncalls = int(rng.integers(1, 4))
     budget = 120_000 // (lines * C)
