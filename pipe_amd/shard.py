@@ -48,7 +48,14 @@ def init(backend: str, rank: int, world: int, device=None):
         # latter if the first RCCL collective fails (the data path has no collective to lose)
         # (no device_id: RCCL's communicator is then made by the first device collective, inside settle()'s try)
         backend = "cpu:gloo,cuda:nccl"
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    except Exception:  # noqa: BLE001 -- e.g. gloo cannot find an interface: RCCL alone then (no fallback to offer)
+        if backend != "cpu:gloo,cuda:nccl":
+            raise
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        dist.init_process_group("nccl", rank=rank, world_size=world, **kw)
     return dist
 
 
@@ -98,7 +105,12 @@ class ProcessSync:
         except Exception as e:  # noqa: BLE001 -- whatever RCCL raised, the bench must still report
             ok, why = 0.0, f"{type(e).__name__}: {e}"
         flag = torch.tensor([ok], dtype=torch.float64)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        try:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        except Exception:  # noqa: BLE001 -- no host-tensor backend in the group (RCCL-only init): nothing to agree through
+            if ok < 1.0:
+                raise RuntimeError(f"RCCL collective failed and no gloo backend to fall back to: {why}")
+            return
         if float(flag.item()) < 1.0:
             self.device = "cpu"
             self.fallback = why or "another rank's RCCL all-reduce failed"
