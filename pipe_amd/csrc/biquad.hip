@@ -61,6 +61,7 @@ struct BiquadArgs {
     double *seg;      // [T][nseries][S][2]: end states of pass 1, start states after pass 2
     int seglen, T;    // frames per segment (the last one may be shorter), segments per series
     int blocks_per_seg;
+    int spb;          // few series (< a workgroup's lanes): segments per workgroup, lanes = (segment, series); 0 = one segment
 };
 
 // zero-input state transition over one segment, row-major (2S x 2S); a kernel argument, so the
@@ -122,18 +123,37 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
               const BiquadCoeffs q)
 {
     // a workgroup never straddles two segments, so the frame count is wave-uniform
-    const int seg = MODE == kWhole ? 0 : (int)(blockIdx.x / (unsigned)a.blocks_per_seg);
+    int seg = MODE == kWhole ? 0 : (int)(blockIdx.x / (unsigned)a.blocks_per_seg);
     const int sblock = MODE == kWhole ? (int)blockIdx.x : (int)(blockIdx.x % (unsigned)a.blocks_per_seg);
-    const int sid = sblock * kThreads + threadIdx.x;
-    const bool live = sid < a.nseries;
+    int sid = sblock * kThreads + threadIdx.x;
+    bool live = sid < a.nseries;
+    int64_t nframes = a.frames;
+    if (MODE != kWhole) {
+        if (a.spb > 0) {
+            // Few series (one long stereo stream has two): a workgroup's lanes are (segment, series) pairs, spb
+            // full-length segments per workgroup, so that every lane has a chain to walk (one segment per
+            // workgroup left all but `nseries` of its lanes idle: 1 Line x 2 ch x 8.4 M frames ran at 22
+            // Gsamples/s).  The series' LAST segment, which may be shorter, has the launch's last workgroup
+            // to itself: the frame count stays uniform over a workgroup.
+            const bool tail = blockIdx.x + 1 == gridDim.x;
+            const int sl = (int)threadIdx.x / a.nseries;
+            sid = (int)threadIdx.x - sl * a.nseries;
+            seg = tail ? a.T - 1 : (int)blockIdx.x * a.spb + sl;
+            live = tail ? (int)threadIdx.x < a.nseries : (sl < a.spb && seg < a.T - 1);
+            nframes = tail ? a.frames - (int64_t)(a.T - 1) * a.seglen : (int64_t)a.seglen;
+        } else {
+            const int64_t f0s = (int64_t)seg * a.seglen;
+            nframes = a.frames - f0s < a.seglen ? a.frames - f0s : (int64_t)a.seglen;
+        }
+    }
     const int sidc = live ? sid : 0;
     const int line = sidc / a.C;
     const int c = sidc - line * a.C;
+    if (!live)
+        seg = 0;
     double *__restrict__ st = MODE == kWhole ? a.state + (int64_t)sidc * a.S * 2
                                              : a.seg + ((int64_t)seg * a.nseries + sidc) * a.S * 2;
     const int64_t f_first = (int64_t)seg * a.seglen;
-    const int64_t nframes = MODE == kWhole ? a.frames
-                                           : (a.frames - f_first < a.seglen ? a.frames - f_first : (int64_t)a.seglen);
     // whole call through 32-bit offsets (the launcher guarantees the buffers are < 4 GiB)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<TIn *>(in_base), 0, (int)a.in_bytes, 0x00020000);
@@ -252,6 +272,225 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
                 st[2 * s] = s1[s];
                 st[2 * s + 1] = s2[s];
             }
+        }
+    }
+}
+
+// ---- time-segmented form through LDS tiles (few channels) -------------------------------------------
+// The kernels above give every lane ONE series and let it walk its frames in place: with many channels per
+// frame neighbouring lanes share cache lines (8 channels, 512 Lines: 400 Gsamples/s), with one or two each lane
+// drags its own line along (74 / 166 Gsamples/s; one long stereo stream: 22).  Here a workgroup takes a TILE of
+// 256 SEG / C consecutive frames of all C channels of a Line (C = 1, 2, 4, 8): staged coalesced into LDS (16 bytes
+// a lane, all of the tile's loads in flight at once), lane (c, g) walks segment g -- SEG frames -- of channel c out
+// of LDS (segments SEG + 1 apart: the lanes on different banks), the 256 / C segments of a channel are chained by
+// a scan inside the workgroup (affine maps with one constant matrix: y_g = A y_{g-1} + z_g, Hillis-Steele with
+// A^(2^k) from a table), and the tiles of a series by the same three passes as above: pass 1 writes a tile's
+// zero-start end state, a scan kernel turns those into the tiles' start states, pass 2 folds the tile's start state
+// into segment 0, scans, walks every segment from its true start state and stores the tile coalesced.  Same
+// arithmetic contract as the lane-walk form (start states through powers of the transition matrix).
+// 280-340 Gsamples/s from 4096 Lines of one buffer to ONE Line of 4096 buffers (scripts/biquad_shapes_probe.py).
+constexpr int kTileThreads = 256;
+// frames per segment: SEG = 32, or 16 where Lines are short against a tile of 32s (4096-frame mono Lines would
+// leave half of every 8192-frame tile empty)
+constexpr int kTilePowers = 8;                 // A^(2^k), k = 0 .. 7 (256 segments of one channel)
+constexpr int kTileMaxSections = 2;
+struct BiquadTilePowers {
+    double m[kTilePowers][2 * kTileMaxSections][2 * kTileMaxSections];
+};
+
+template <typename T>
+struct TileVec;
+template <>
+struct TileVec<float> {
+    struct __attribute__((packed, aligned(4))) type {
+        float v[4];
+    };
+};
+template <>
+struct TileVec<double> {
+    struct __attribute__((aligned(8))) type {
+        double v[2];
+    };
+};
+// what a tile is staged as: float32 when the call reads and writes float32 (half the LDS: three workgroups on a CU)
+template <typename TIn, typename TOut>
+using TileStage = typename std::conditional<sizeof(TIn) == 4 && sizeof(TOut) == 4, float, double>::type;
+
+template <typename TIn, typename TOut, int NS, bool GAIN, int MODE, int SEG>
+__global__ void __launch_bounds__(kTileThreads)
+biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a, const BiquadCoeffs q,
+                   const BiquadTilePowers pw, int tiles_per_line, int clog)
+{
+    constexpr int N = 2 * NS;
+    constexpr int kTileSeg = SEG, kTileElems = kTileThreads * SEG, kSegLog = SEG == 32 ? 5 : 4;
+    using TS = TileStage<TIn, TOut>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *yb = reinterpret_cast<double *>(smem_raw);                 // [256][N]: the scan's exchange
+    TS *xs = reinterpret_cast<TS *>(yb + kTileThreads * N);            // [256 segments][kTileSeg + 1]
+    const int tid = (int)threadIdx.x;
+    const int line = (int)blockIdx.x / tiles_per_line;
+    const int tile = (int)blockIdx.x - line * tiles_per_line;
+    const int C = 1 << clog, spc = kTileThreads >> clog;              // channels; segments per channel in a tile
+    const int tfr = kTileElems >> clog;                                // frames per tile
+    const int64_t f0 = (int64_t)tile * tfr;
+    const int nreal = (int)(a.frames - f0 < tfr ? a.frames - f0 : tfr);  // frames of this tile inside the Line
+    const TIn *__restrict__ in = in_base + ((int64_t)line * a.frames + f0) * C;
+    // element e of the tile = frame e / C, channel e % C -> segment (c, frame / 32), position frame % 32
+    auto cell = [&](int e) {
+        const int ft = e >> clog, cc = e & (C - 1);
+        return (cc * spc + (ft >> kSegLog)) * (kTileSeg + 1) + (ft & (kTileSeg - 1));
+    };
+
+    // ---- stage (coalesced, 16 bytes a lane; every load of the tile in flight before the first LDS write)
+    const int nel = nreal << clog;  // elements of the tile inside the Line
+    {
+        using V = typename TileVec<TIn>::type;
+        constexpr int VW = 16 / (int)sizeof(TIn), NCH = kTileElems / (kTileThreads * VW);
+        if (nreal == tfr || nel % VW == 0) {
+            const V *__restrict__ vin = reinterpret_cast<const V *>(in);
+            V v[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = tid + i * kTileThreads;
+                if (nreal == tfr || ch * VW < nel)
+                    v[i] = vin[ch];
+                else
+                    v[i] = V{};
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int u = 0; u < VW; ++u)
+                    xs[cell((tid + i * kTileThreads) * VW + u)] = (TS)v[i].v[u];
+        } else {
+            for (int e = tid; e < kTileElems; e += kTileThreads)
+                xs[cell(e)] = e < nel ? (TS)in[e] : (TS)0;
+        }
+    }
+    __syncthreads();
+
+    const int c = tid / spc, g = tid - c * spc;        // my channel, my segment of it
+    const int nfr = nreal - g * kTileSeg < 0 ? 0 : (nreal - g * kTileSeg < kTileSeg ? nreal - g * kTileSeg : kTileSeg);
+    const int64_t series = (int64_t)line * C + c;
+    TS *__restrict__ col = xs + tid * (kTileSeg + 1);
+    double s1[kMaxSections], s2[kMaxSections];
+    auto walk = [&](bool write) {
+#pragma unroll
+        for (int i = 0; i < kTileSeg; ++i) {
+            if (i < nfr) {
+                double y = biquad_step<NS>((double)col[i], s1, s2, q);
+                if (write) {
+                    if constexpr (GAIN)
+                        y = y * a.gain;
+                    col[i] = (TS)y;  // (float32 staging only with float32 results: this is the result's rounding)
+                }
+            }
+        }
+    };
+    // ---- zero-start end state of my segment
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        s1[k] = s2[k] = 0.0;
+    walk(false);
+    double y[N];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        y[2 * k] = s1[k];
+        y[2 * k + 1] = s2[k];
+    }
+    double *__restrict__ tstate = a.seg + ((int64_t)tile * a.nseries + series) * N;
+    if (MODE == kSegFinal && g == 0) {  // the tile's true start state rides into segment 0: y_0 = A t0 + z_0
+        double t0[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            t0[i] = tstate[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                y[i] = __builtin_fma(pw.m[0][i][j], t0[j], y[i]);
+    }
+    // ---- inclusive scan over the channel's segments: y_g += A^(2^k) y_(g - 2^k)
+#pragma unroll
+    for (int k = 0; k < kTilePowers; ++k) {
+        const int d = 1 << k;
+        if (d >= spc)
+            break;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            yb[tid * N + i] = y[i];
+        __syncthreads();
+        if (g >= d) {
+            double o[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                o[i] = yb[(tid - d) * N + i];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    y[i] = __builtin_fma(pw.m[k][i][j], o[j], y[i]);
+        }
+        __syncthreads();
+    }
+    // my segment's start state: the inclusive value of the segment before (segment 0: the tile's start state)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        yb[tid * N + i] = y[i];
+    __syncthreads();
+    double st0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        st0[i] = g > 0 ? yb[(tid - 1) * N + i] : (MODE == kSegFinal ? tstate[i] : 0.0);
+    if constexpr (MODE == kSegZeroState) {
+        // the tile's zero-start end state: after the tile's last real frame.  A full last segment: its inclusive
+        // value; a partial one: walked again from its start state (its own map is not A)
+        const int gl = (nreal - 1) >> kSegLog;  // owner of the last real frame (nreal >= 1: the grid covers real tiles only)
+        if (g == gl) {
+            if (nfr == kTileSeg) {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    tstate[i] = y[i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    s1[k] = st0[2 * k];
+                    s2[k] = st0[2 * k + 1];
+                }
+                walk(false);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    tstate[2 * k] = s1[k];
+                    tstate[2 * k + 1] = s2[k];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            s1[k] = st0[2 * k];
+            s2[k] = st0[2 * k + 1];
+        }
+        walk(true);
+        __syncthreads();
+        TOut *__restrict__ out = out_base + ((int64_t)line * a.frames + f0) * C;
+        using V = typename TileVec<TOut>::type;
+        constexpr int VW = 16 / (int)sizeof(TOut), NCH = kTileElems / (kTileThreads * VW);
+        if (nreal == tfr || nel % VW == 0) {
+            V *__restrict__ vout = reinterpret_cast<V *>(out);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = tid + i * kTileThreads;
+                V v;
+#pragma unroll
+                for (int u = 0; u < VW; ++u)
+                    v.v[u] = (TOut)xs[cell(ch * VW + u)];
+                if (nreal == tfr || ch * VW < nel)
+                    vout[ch] = v;
+            }
+        } else {
+            for (int e = tid; e < nel; e += kTileThreads)
+                out[e] = (TOut)xs[cell(e)];
         }
     }
 }
@@ -619,6 +858,133 @@ biquad_scan_kernel(const BiquadArgs a, const BiquadTransition mfull, const Biqua
         st[i] = s[i];
 }
 
+// The same pass for MANY tiles of few series (one long stream: thousands of tiles, the lane above walks them one
+// after the other at a memory round trip per chunk): one wave per series, lane l owns the R consecutive tiles
+// l R .. l R + R - 1.  Every lane folds its own tiles from zero state, the 64 partial results are chained by a scan
+// over the lanes (every lane's map is z + M^R s, so the scan needs only (M^R)^(2^j), j = 0 .. 5 -- a table from the
+// host), and every lane walks its tiles again from its true start state.  (Lanes past the last tile, and the short
+// range of the last used lane, never feed another lane.)
+struct BiquadScanPowers {
+    double m[6][2 * kTileMaxSections][2 * kTileMaxSections];
+};
+template <int N>
+__global__ void __launch_bounds__(64)
+biquad_scan_wave_kernel(const BiquadArgs a, const BiquadTransition mfull, const BiquadTransition mlast,
+                        const BiquadScanPowers sp, int R)
+{
+    const int sid = (int)blockIdx.x, lane = (int)threadIdx.x;
+    double *__restrict__ st = a.state + (int64_t)sid * N;
+    const int64_t stride = (int64_t)a.nseries * N;
+    double *__restrict__ zbase = a.seg + (int64_t)sid * N;
+    const int k0 = lane * R < a.T ? lane * R : a.T, k1 = k0 + R < a.T ? k0 + R : a.T;
+    constexpr int kU = 8;
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        y[i] = 0.0;
+    for (int kk = k0; kk < k1; kk += kU) {
+        double z[kU][N];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = kk + u < k1 ? kk + u : k1 - 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                z[u][i] = zbase[k * stride + i];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (kk + u < k1) {
+                double nx[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = z[u][i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        acc = __builtin_fma(mfull.m[i][j], y[j], acc);
+                    nx[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    y[i] = nx[i];
+            }
+    }
+    double s0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        s0[i] = st[i];
+    if (lane == 0) {  // the series' carried state rides in with lane 0: Y_0 = y_0 + M^R s0
+        double nx[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double acc = y[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                acc = __builtin_fma(sp.m[0][i][j], s0[j], acc);
+            nx[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            y[i] = nx[i];
+    }
+#pragma unroll
+    for (int jp = 0; jp < 6; ++jp) {
+        const int d = 1 << jp;
+        double o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            o[i] = __shfl_up(y[i], d, 64);
+        if (lane >= d) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    y[i] = __builtin_fma(sp.m[jp][i][j], o[j], y[i]);
+        }
+    }
+    double s[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double prev = __shfl_up(y[i], 1, 64);
+        s[i] = lane == 0 ? s0[i] : prev;
+    }
+    for (int kk = k0; kk < k1; kk += kU) {
+        double z[kU][N];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = kk + u < k1 ? kk + u : k1 - 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                z[u][i] = zbase[k * stride + i];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = kk + u;
+            if (k < k1) {
+                const BiquadTransition &m = k == a.T - 1 ? mlast : mfull;
+                double nx[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = z[u][i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        acc = __builtin_fma(m.m[i][j], s[j], acc);
+                    nx[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    zbase[k * stride + i] = s[i];
+                    s[i] = nx[i];
+                }
+            }
+        }
+    }
+    if (k1 == a.T && k0 < k1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            st[i] = s[i];
+    }
+}
+
 class Biquad final : public pipe_hip_processor {
 public:
     int init(const double *coeffs, int32_t nsections)
@@ -651,7 +1017,9 @@ public:
         if (param != PIPE_HIP_PARAM_COEFFS || count != 5 * S_ || !values)
             return PIPE_HIP_EINVAL;
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
-        mfull_len_ = -1;
+        mfull_len_ = mlast_len_ = sp_len_ = -1;
+        kappa_ = -1.0;
+        pw_seg_ = -1;
         return PIPE_HIP_OK;
     }
     // a gain stage that directly follows this biquad in a chain is folded into the
@@ -684,13 +1052,17 @@ public:
         // time-segmented form: float32 results (or float64 intermediates of a float32 chain)
         // only, and only when the series alone cannot fill the machine
         // (the relaxed forms carry states through powers of the transition matrix: stable sections only)
-        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && stable();
+        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && relaxed_ok();
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
         bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
                          frames * a.nseries >= seg_min_samples_;
         if (segmented) {
+            // few series: lanes are (segment, series) pairs, more and shorter segments (the serial scan over them
+            // bounds their number)
+            a.spb = a.nseries < kThreads && !std::getenv("PIPE_HIP_BIQUAD_SEG_ONE_PER_BLOCK") ? kThreads / a.nseries : 0;
+            const int tmax = a.spb > 0 ? 4096 : 1024;
             int T = (int)(frames / 64);
-            T = T < 2 ? 2 : (T > 1024 ? 1024 : T);
+            T = T < 2 ? 2 : (T > tmax ? tmax : T);
             int64_t seglen = (frames + T - 1) / T;
             seglen = (seglen + kChunk - 1) / kChunk * kChunk;
             T = (int)((frames + seglen - 1) / seglen);
@@ -699,8 +1071,100 @@ public:
             a.T = T;
             a.blocks_per_seg = (int)sblocks;
         }
+        // few channels (1, 2, 4, 8) and one or two sections: the LDS-tiled form (coalesced; the lane walks are not)
+        const int clog = cfg.channels == 1 ? 0 : cfg.channels == 2 ? 1 : cfg.channels == 4 ? 2 : cfg.channels == 8 ? 3 : -1;
+        const bool tiled = relaxed && S_ <= kTileMaxSections && clog >= 0 && frames * a.nseries >= seg_min_samples_ &&
+                           frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
+                           !(cfg.channels == 8 && nl >= kTileWalkLines && segmented);  // (many 8-channel Lines: the lane walk, 400 against 340)
         PH_TRY(timer.begin(s));
-        if (segmented) {
+        if (tiled) {
+            // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
+            const int64_t t32 = (256 * 32) >> clog, t16 = (256 * 16) >> clog;
+            const int64_t waste32 = (frames + t32 - 1) / t32 * t32 - frames, waste16 = (frames + t16 - 1) / t16 * t16 - frames;
+            const int seg = waste32 - waste16 > frames / 4 && !std::getenv("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32;
+            const int tfr = (int)(seg == 32 ? t32 : t16);
+            a.T = (int)((frames + tfr - 1) / tfr);
+            a.seglen = tfr;
+            const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
+            if (seg_.bytes < need)
+                PH_TRY(seg_.alloc(need));
+            a.seg = static_cast<double *>(seg_.p);
+            if (mfull_len_ != tfr) {
+                transition(tfr, &mfull_);
+                mfull_len_ = tfr;
+            }
+            if (pw_seg_ != seg) {
+                for (int k = 0; k < kTilePowers; ++k) {
+                    BiquadTransition m;
+                    transition(seg << k, &m);
+                    for (int i = 0; i < 2 * kTileMaxSections; ++i)
+                        for (int j = 0; j < 2 * kTileMaxSections; ++j)
+                            pw_.m[k][i][j] = m.m[i][j];
+                }
+                pw_seg_ = seg;
+            }
+            const int last_len = (int)(frames - (int64_t)(a.T - 1) * tfr);
+            if (mlast_len_ != last_len) {
+                if (last_len == tfr)
+                    mlast_ = mfull_;
+                else
+                    transition(last_len, &mlast_);
+                mlast_len_ = last_len;
+            }
+            const dim3 tgrid((unsigned)a.T * (unsigned)nl);
+            const size_t lds_rest = sizeof(double) * (size_t)kTileThreads * 2u * (size_t)S_;
+#define PH_BT4(TI, TO, NSV, G, SEGV)                                                                                       \
+    do {                                                                                                              \
+        const size_t lds = lds_rest + sizeof(TileStage<TI, TO>) * (size_t)kTileThreads * (SEGV + 1);                 \
+        auto k1 = biquad_tile_kernel<TI, TO, NSV, G, kSegZeroState, SEGV>;                                            \
+        auto k2 = biquad_tile_kernel<TI, TO, NSV, G, kSegFinal, SEGV>;                                                \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                   (int)lds));                                                                        \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                   (int)lds));                                                                        \
+        hipLaunchKernelGGL(k1, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, clog);                                          \
+        if (a.T > kWaveScanMinTiles && !std::getenv("PIPE_HIP_BIQUAD_NO_WAVE_SCAN"))                                \
+            launch_scan_wave(s, a);                                                                                   \
+        else                                                                                                          \
+            launch_scan(sblocks, s, a, mlast_);                                                                       \
+        hipLaunchKernelGGL(k2, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, clog);                                          \
+    } while (0)
+#define PH_BT3(TI, TO, NSV, G)                 \
+    do {                                       \
+        if (seg == 32)                         \
+            PH_BT4(TI, TO, NSV, G, 32);        \
+        else                                   \
+            PH_BT4(TI, TO, NSV, G, 16);        \
+    } while (0)
+#define PH_BT(TI, TO, NAME)                    \
+    do {                                       \
+        if (has_gain_) {                       \
+            if (S_ == 1)                       \
+                PH_BT3(TI, TO, 1, true);       \
+            else                               \
+                PH_BT3(TI, TO, 2, true);       \
+        } else {                               \
+            if (S_ == 1)                       \
+                PH_BT3(TI, TO, 1, false);      \
+            else                               \
+                PH_BT3(TI, TO, 2, false);      \
+        }                                      \
+        last_kernel = NAME;                    \
+    } while (0)
+            if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32)
+                PH_BT(float, float, "biquad_tile_kernel<f32,f32,segmented>");
+            else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64)
+                PH_BT(double, double, "biquad_tile_kernel<f64,f64,segmented>");
+            else if (in_dtype == PIPE_HIP_F32)
+                PH_BT(float, double, "biquad_tile_kernel<f32,f64,segmented>");
+            else
+                PH_BT(double, float, "biquad_tile_kernel<f64,f32,segmented>");
+#undef PH_BT
+#undef PH_BT3
+#undef PH_BT4
+        } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
                 PH_TRY(seg_.alloc(need));
@@ -715,7 +1179,7 @@ public:
                 mlast = mfull_;
             else
                 transition((int)last_len, &mlast);
-            const dim3 sgrid(sblocks * (unsigned)a.T);
+            const dim3 sgrid(a.spb > 0 ? (unsigned)((a.T - 1 + a.spb - 1) / a.spb + 1) : sblocks * (unsigned)a.T);
 #define PH_BQ3(TI, TO, NSV, G)                                                                         \
     do {                                                                                               \
         hipLaunchKernelGGL((biquad_kernel<TI, TO, NSV, G, kSegZeroState>), sgrid, dim3(kThreads), 0, s, \
@@ -891,7 +1355,7 @@ public:
         v->state = static_cast<double *>(state_.p);
         v->coeffs = &q_.c[0][0];
         v->sections = S_;
-        v->relaxed = !exact_ && !env_exact_ && stable();
+        v->relaxed = !exact_ && !env_exact_ && relaxed_ok();
         return true;
     }
 
@@ -907,6 +1371,50 @@ public:
         }
         return true;
     }
+
+    // How far the relaxed forms' float64 values sit from the oracle's.  They rebuild a segment's start state as
+    // M^k s + (the segment walked from zero); the oracle walks on from s.  Equal in exact arithmetic; in float64 the
+    // two differ by the recurrence's own rounding noise, which a resonant section amplifies: an error in the state
+    // comes back k frames later times the entries of M^k, up to ~1 / sin(w0) for poles at angle w0 (21 for the
+    // 300 Hz, Q = 4 test section at 48 kHz: measured 3e-14 of full scale, about 14 kappa eps -- the oracle's own
+    // distance from the exact result is of the same size).  kappa = the largest entry of any power of the
+    // one-frame transition matrix.  The bound include/pipe_hip.h states scales with it (one float32 ulp measured
+    // at max(|y|, 2^-22 kappa x full scale)); cascades with kappa above kMaxKappa -- poles within ~1e-3 rad of
+    // z = 1 -- keep the ordered recurrence.
+    static constexpr double kMaxKappa = 1024.0;
+    double kappa()
+    {
+        if (kappa_ >= 0.0)
+            return kappa_;
+        BiquadTransition m1;
+        transition(1, &m1);
+        const int n = 2 * S_;
+        double p[2 * kMaxSegSections][2 * kMaxSegSections], t[2 * kMaxSegSections][2 * kMaxSegSections];
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                p[i][j] = m1.m[i][j];
+        double worst = 0.0;
+        for (int k = 1; k <= 65536; ++k) {
+            double mx = 0.0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    mx = std::fmax(mx, std::fabs(p[i][j]));
+            worst = std::fmax(worst, mx);
+            if (!(worst <= kMaxKappa) || (k > 64 && mx < 1e-3 * worst))
+                break;  // (past the limit, or decayed past its peak)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0.0;
+                    for (int l = 0; l < n; ++l)
+                        acc += p[i][l] * m1.m[l][j];
+                    t[i][j] = acc;
+                }
+            std::memcpy(p, t, sizeof p);
+        }
+        kappa_ = worst;
+        return kappa_;
+    }
+    bool relaxed_ok() { return stable() && S_ <= kMaxSegSections && kappa() <= kMaxKappa; }  // (no relaxed form takes more sections)
 
     // The LDS-staged exact kernel runs one workgroup per Line: it wins when Lines are few enough
     // that the register form cannot fill its waves anyway (always the case for the per-buffer
@@ -962,6 +1470,52 @@ public:
         }
     }
 
+    // (tile form, many tiles) one wave per series; the table (M^R)^(2^j) by squaring in long double
+    static constexpr int kWaveScanMinTiles = 32;
+    static constexpr int kTileWalkLines = 256;
+    void launch_scan_wave(hipStream_t s, const BiquadArgs &a)
+    {
+        const int R = (a.T + 63) / 64, n = 2 * S_;
+        if (sp_len_ != mfull_len_ || sp_R_ != R) {
+            long double b[4][4], r[4][4], t[4][4];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    b[i][j] = mfull_.m[i][j];
+                    r[i][j] = i == j ? 1.0L : 0.0L;
+                }
+            auto mul = [&](long double(*x)[4], long double(*y)[4]) {  // x = x * y
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        long double acc = 0.0L;
+                        for (int k = 0; k < n; ++k)
+                            acc += x[i][k] * y[k][j];
+                        t[i][j] = acc;
+                    }
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j)
+                        x[i][j] = t[i][j];
+            };
+            for (int e = R; e > 0; e >>= 1) {
+                if (e & 1)
+                    mul(r, b);
+                mul(b, b);
+            }
+            std::memset(&sp_, 0, sizeof sp_);
+            for (int jp = 0; jp < 6; ++jp) {
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j)
+                        sp_.m[jp][i][j] = (double)r[i][j];
+                mul(r, r);
+            }
+            sp_len_ = mfull_len_;
+            sp_R_ = R;
+        }
+        if (S_ == 1)
+            hipLaunchKernelGGL(biquad_scan_wave_kernel<2>, dim3((unsigned)a.nseries), dim3(64), 0, s, a, mfull_, mlast_, sp_, R);
+        else
+            hipLaunchKernelGGL(biquad_scan_wave_kernel<4>, dim3((unsigned)a.nseries), dim3(64), 0, s, a, mfull_, mlast_, sp_, R);
+    }
+
     // zero-input transition of the cascade over `len` frames: column j = the state after len
     // frames of silence started from unit state j (order s1_0, s2_0, s1_1, s2_1, ...)
     void transition(int len, BiquadTransition *m) const
@@ -999,8 +1553,16 @@ private:
     const int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))
                                          : (int64_t)1 << 20;
-    BiquadTransition mfull_{};
-    int mfull_len_ = -1;
+    const int64_t tile_min_frames_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
+                                         ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES"))
+                                         : 4 * kChunk;
+    BiquadTransition mfull_{}, mlast_{};
+    int mfull_len_ = -1, mlast_len_ = -1;  // (the lane-walk form computes its own last-segment matrix per call)
+    BiquadTilePowers pw_{};
+    int pw_seg_ = -1;
+    double kappa_ = -1.0;
+    BiquadScanPowers sp_{};
+    int sp_len_ = -1, sp_R_ = -1;
 };
 
 }  // namespace

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""The time-segmented biquad (large float32 calls) over shapes of the same sample count: many Lines of few
+frames to ONE long stream.  scripts/biquad_shapes_probe.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pipe_amd import processors as P, synth  # noqa: E402
+
+F = 4096
+st = torch.cuda.Stream()
+S = int(os.environ.get("PROBE_SECTIONS", "1"))
+q = np.vstack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(fc=4000.0, q=1.3)][:S])
+for lines, C, K in ((4096, 1, 1), (2048, 2, 1), (512, 8, 1), (64, 2, 32), (8, 2, 256), (1, 2, 2048), (64, 1, 64), (1, 1, 4096), (1, 8, 512)):
+    n = lines * K * F * C
+    d_in = torch.empty(n, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(0))
+    d_out = torch.empty_like(d_in)
+    with P.Biquad(q, F, C, dtype=np.float32, lines=lines, max_batch=K) as p:
+        p.start()
+        for _ in range(10):
+            p.process_batch(d_in, d_out, K * F, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            p.process_batch(d_in, d_out, K * F, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 50
+        print(f"biquad {lines:5d} Lines x {C} ch x {K:4d} buffers: {p.kernel_name():36s} {dt * 1e3:8.4f} ms  {n / dt / 1e9:7.1f} Gsamples/s", flush=True)
