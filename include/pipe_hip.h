@@ -68,13 +68,15 @@ typedef enum pipe_hip_param {
                                   biquad's relaxed forms propagate segment states through powers of
                                   the state-transition matrix, which a resonant section makes
                                   ill-conditioned: their float64 value differs from the oracle's by
-                                  ~14 kappa * 2^-53 of the Line's full-scale output, kappa = the
+                                  the recurrence's own rounding noise -- up to ~200 kappa * 2^-53 of
+                                  the Line's full-scale output at single samples, kappa = the
                                   largest entry of any power of the cascade's one-frame transition
                                   matrix (about 1 / sin(w0) for poles at angle w0: 4 for the 1 kHz
-                                  Butterworth section, 21 for 300 Hz with Q = 4, at 48 kHz) -- the
-                                  size of the oracle's own rounding error.  Their float32 result is
-                                  within one ulp measured at max(|y|, 2^-22 * kappa * max|y| of the
-                                  Line) (tests/test_gpu_biquad_seg.py).  A cascade with kappa > 1024
+                                  Butterworth section, 21 for 300 Hz with Q = 4, at 48 kHz); the
+                                  oracle's own distance from the exact result is of that size.
+                                  Their float32 result is within one ulp measured at
+                                  max(|y|, 2^-19 * kappa * max|y| of the
+                                  Line) (tests/test_gpu_biquad_seg.py, scripts/stress_biquad_seg.py).  A cascade with kappa > 1024
                                   or with a section whose poles are not strictly inside the unit
                                   circle always takes the exact form.
                                   float64 buffers always take the exact form.

@@ -1376,10 +1376,10 @@ public:
     // M^k s + (the segment walked from zero); the oracle walks on from s.  Equal in exact arithmetic; in float64 the
     // two differ by the recurrence's own rounding noise, which a resonant section amplifies: an error in the state
     // comes back k frames later times the entries of M^k, up to ~1 / sin(w0) for poles at angle w0 (21 for the
-    // 300 Hz, Q = 4 test section at 48 kHz: measured 3e-14 of full scale, about 14 kappa eps -- the oracle's own
+    // 300 Hz, Q = 4 test section at 48 kHz: measured 3e-14 of full scale on a 614 K-frame stream; the soak test's worst 190 kappa eps, with kappa 88 -- the noise is a random sum over the resonance's decay time; the oracle's own
     // distance from the exact result is of the same size).  kappa = the largest entry of any power of the
     // one-frame transition matrix.  The bound include/pipe_hip.h states scales with it (one float32 ulp measured
-    // at max(|y|, 2^-22 kappa x full scale)); cascades with kappa above kMaxKappa -- poles within ~1e-3 rad of
+    // at max(|y|, 2^-19 kappa x full scale)); cascades with kappa above kMaxKappa -- poles within ~1e-3 rad of
     // z = 1 -- keep the ordered recurrence.
     static constexpr double kMaxKappa = 1024.0;
     double kappa()
