@@ -280,7 +280,7 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
 // The kernels above give every lane ONE series and let it walk its frames in place: with many channels per
 // frame neighbouring lanes share cache lines (8 channels, 512 Lines: 400 Gsamples/s), with one or two each lane
 // drags its own line along (74 / 166 Gsamples/s; one long stereo stream: 22).  Here a workgroup takes a TILE of
-// 256 SEG / C consecutive frames of all C channels of a Line (C = 1, 2, 4, 8): staged coalesced into LDS (16 bytes
+// (256 / C) SEG consecutive frames of all C channels of a Line (C <= 8): staged coalesced into LDS (16 bytes
 // a lane, all of the tile's loads in flight at once), lane (c, g) walks segment g -- SEG frames -- of channel c out
 // of LDS (segments SEG + 1 apart: the lanes on different banks), the 256 / C segments of a channel are chained by
 // a scan inside the workgroup (affine maps with one constant matrix: y_g = A y_{g-1} + z_g, Hillis-Steele with
@@ -319,7 +319,7 @@ using TileStage = typename std::conditional<sizeof(TIn) == 4 && sizeof(TOut) == 
 template <typename TIn, typename TOut, int NS, bool GAIN, int MODE, int SEG>
 __global__ void __launch_bounds__(kTileThreads)
 biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a, const BiquadCoeffs q,
-                   const BiquadTilePowers pw, int tiles_per_line, int clog)
+                   const BiquadTilePowers pw, int tiles_per_line, int C, int spc, int cmagic)
 {
     constexpr int N = 2 * NS;
     constexpr int kTileSeg = SEG, kTileElems = kTileThreads * SEG, kSegLog = SEG == 32 ? 5 : 4;
@@ -330,29 +330,31 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     const int tid = (int)threadIdx.x;
     const int line = (int)blockIdx.x / tiles_per_line;
     const int tile = (int)blockIdx.x - line * tiles_per_line;
-    const int C = 1 << clog, spc = kTileThreads >> clog;              // channels; segments per channel in a tile
-    const int tfr = kTileElems >> clog;                                // frames per tile
+    // C channels (1 .. 8); spc = 256 / C segments per channel in a tile (lanes past C spc idle when C is not a power
+    // of two); e / C for e < 9362 as (e cmagic) >> 16, cmagic = ceil(65536 / C)
+    const int tfr = spc * kTileSeg;                                    // frames per tile
+    const int nelt = tfr * C;                                          // elements per tile (<= kTileElems)
     const int64_t f0 = (int64_t)tile * tfr;
     const int nreal = (int)(a.frames - f0 < tfr ? a.frames - f0 : tfr);  // frames of this tile inside the Line
     const TIn *__restrict__ in = in_base + ((int64_t)line * a.frames + f0) * C;
     // element e of the tile = frame e / C, channel e % C -> segment (c, frame / 32), position frame % 32
     auto cell = [&](int e) {
-        const int ft = e >> clog, cc = e & (C - 1);
+        const int ft = (int)(((unsigned)e * (unsigned)cmagic) >> 16), cc = e - ft * C;
         return (cc * spc + (ft >> kSegLog)) * (kTileSeg + 1) + (ft & (kTileSeg - 1));
     };
 
     // ---- stage (coalesced, 16 bytes a lane; every load of the tile in flight before the first LDS write)
-    const int nel = nreal << clog;  // elements of the tile inside the Line
+    const int nel = nreal * C;  // elements of the tile inside the Line
     {
         using V = typename TileVec<TIn>::type;
         constexpr int VW = 16 / (int)sizeof(TIn), NCH = kTileElems / (kTileThreads * VW);
-        if (nreal == tfr || nel % VW == 0) {
+        if (nel % VW == 0) {
             const V *__restrict__ vin = reinterpret_cast<const V *>(in);
             V v[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = tid + i * kTileThreads;
-                if (nreal == tfr || ch * VW < nel)
+                if (ch * VW < nel)
                     v[i] = vin[ch];
                 else
                     v[i] = V{};
@@ -360,17 +362,21 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
 #pragma unroll
-                for (int u = 0; u < VW; ++u)
-                    xs[cell((tid + i * kTileThreads) * VW + u)] = (TS)v[i].v[u];
+                for (int u = 0; u < VW; ++u) {
+                    const int e = (tid + i * kTileThreads) * VW + u;
+                    if (e < nelt)
+                        xs[cell(e)] = (TS)v[i].v[u];
+                }
         } else {
-            for (int e = tid; e < kTileElems; e += kTileThreads)
+            for (int e = tid; e < nelt; e += kTileThreads)
                 xs[cell(e)] = e < nel ? (TS)in[e] : (TS)0;
         }
     }
     __syncthreads();
 
-    const int c = tid / spc, g = tid - c * spc;        // my channel, my segment of it
-    const int nfr = nreal - g * kTileSeg < 0 ? 0 : (nreal - g * kTileSeg < kTileSeg ? nreal - g * kTileSeg : kTileSeg);
+    const bool active = tid < C * spc;
+    const int c = active ? tid / spc : 0, g = active ? tid - c * spc : 0;  // my channel, my segment of it
+    const int nfr = !active || nreal - g * kTileSeg < 0 ? 0 : (nreal - g * kTileSeg < kTileSeg ? nreal - g * kTileSeg : kTileSeg);
     const int64_t series = (int64_t)line * C + c;
     TS *__restrict__ col = xs + tid * (kTileSeg + 1);
     double s1[kMaxSections], s2[kMaxSections];
@@ -446,7 +452,7 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         // the tile's zero-start end state: after the tile's last real frame.  A full last segment: its inclusive
         // value; a partial one: walked again from its start state (its own map is not A)
         const int gl = (nreal - 1) >> kSegLog;  // owner of the last real frame (nreal >= 1: the grid covers real tiles only)
-        if (g == gl) {
+        if (active && g == gl) {
             if (nfr == kTileSeg) {
 #pragma unroll
                 for (int i = 0; i < N; ++i)
@@ -476,7 +482,7 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         TOut *__restrict__ out = out_base + ((int64_t)line * a.frames + f0) * C;
         using V = typename TileVec<TOut>::type;
         constexpr int VW = 16 / (int)sizeof(TOut), NCH = kTileElems / (kTileThreads * VW);
-        if (nreal == tfr || nel % VW == 0) {
+        if (nel % VW == 0) {
             V *__restrict__ vout = reinterpret_cast<V *>(out);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -484,8 +490,8 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 V v;
 #pragma unroll
                 for (int u = 0; u < VW; ++u)
-                    v.v[u] = (TOut)xs[cell(ch * VW + u)];
-                if (nreal == tfr || ch * VW < nel)
+                    v.v[u] = (TOut)xs[ch * VW + u < nelt ? cell(ch * VW + u) : 0];
+                if (ch * VW < nel)
                     vout[ch] = v;
             }
         } else {
@@ -1071,15 +1077,15 @@ public:
             a.T = T;
             a.blocks_per_seg = (int)sblocks;
         }
-        // few channels (1, 2, 4, 8) and one or two sections: the LDS-tiled form (coalesced; the lane walks are not)
-        const int clog = cfg.channels == 1 ? 0 : cfg.channels == 2 ? 1 : cfg.channels == 4 ? 2 : cfg.channels == 8 ? 3 : -1;
-        const bool tiled = relaxed && S_ <= kTileMaxSections && clog >= 0 && frames * a.nseries >= seg_min_samples_ &&
+        // up to 8 channels and one or two sections: the LDS-tiled form (coalesced; the lane walks are not)
+        const int tc = cfg.channels, tspc = tc <= 8 ? kTileThreads / tc : 0;
+        const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
                            frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
-                           !(cfg.channels == 8 && nl >= kTileWalkLines && segmented);  // (many 8-channel Lines: the lane walk, 400 against 340)
+                           !(cfg.channels >= kTileWalkChannels && nl >= kTileWalkLines && segmented);  // (many Lines of many channels: the lane walk)
         PH_TRY(timer.begin(s));
         if (tiled) {
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
-            const int64_t t32 = (256 * 32) >> clog, t16 = (256 * 16) >> clog;
+            const int64_t t32 = tspc * 32, t16 = tspc * 16;
             const int64_t waste32 = (frames + t32 - 1) / t32 * t32 - frames, waste16 = (frames + t16 - 1) / t16 * t16 - frames;
             const int seg = waste32 - waste16 > frames / 4 && !std::getenv("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32;
             const int tfr = (int)(seg == 32 ? t32 : t16);
@@ -1123,13 +1129,13 @@ public:
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                    (int)lds));                                                                        \
         hipLaunchKernelGGL(k1, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
-                           static_cast<TO *>(d_out), a, q_, pw_, a.T, clog);                                          \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, (65536 + tc - 1) / tc);                                          \
         if (a.T > kWaveScanMinTiles && !std::getenv("PIPE_HIP_BIQUAD_NO_WAVE_SCAN"))                                \
             launch_scan_wave(s, a);                                                                                   \
         else                                                                                                          \
             launch_scan(sblocks, s, a, mlast_);                                                                       \
         hipLaunchKernelGGL(k2, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
-                           static_cast<TO *>(d_out), a, q_, pw_, a.T, clog);                                          \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, (65536 + tc - 1) / tc);                                          \
     } while (0)
 #define PH_BT3(TI, TO, NSV, G)                 \
     do {                                       \
@@ -1472,7 +1478,7 @@ public:
 
     // (tile form, many tiles) one wave per series; the table (M^R)^(2^j) by squaring in long double
     static constexpr int kWaveScanMinTiles = 32;
-    static constexpr int kTileWalkLines = 256;
+    static constexpr int kTileWalkLines = 256, kTileWalkChannels = 6;  // (512 Lines x 6 ch: 250 against 224; x 8 ch: 404 against 338; 1024 x 3 ch: 192 against 214)
     void launch_scan_wave(hipStream_t s, const BiquadArgs &a)
     {
         const int R = (a.T + 63) / 64, n = 2 * S_;

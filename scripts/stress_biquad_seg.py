@@ -23,7 +23,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 kinds, worst = {}, 0.0
 for it in range(iters):
-    C = int(rng.choice([1, 2, 4, 8, 2, 1, 3, 6]))
+    C = int(rng.choice([1, 2, 4, 8, 2, 1, 3, 6, 5, 7, 9, 12]))
     lines = int(rng.choice([1, 1, 2, 5, 37, 300]))
     S = int(rng.choice([1, 2, 2, 3]))
     q = np.vstack([synth.biquad_rbj_lowpass(fc=float(np.exp(rng.uniform(np.log(60.0), np.log(12000.0)))),

@@ -122,11 +122,15 @@ def test_segmented_matches_oracle_within_one_ulp(sections, lines, channels, fram
     (1, 1, 1 << 20, 2),         # 64 tiles a call: chained by the wave scan, one tile a lane
     (1, 2, 4096 * 150 + 77, 1), # 151 tiles: three a lane, the last lanes idle
     (3, 8, 1024 * 333, 1),      # 24 series x 333 tiles: six a lane, the last used lane short
+    (2, 3, 2720 * 3 + 11, 2),   # 3 channels: 85 segments a channel, one lane of 256 idle
+    (1, 6, 1344 * 40, 1),       # 6 channels (42 segments a channel), 40 tiles: the wave scan
+    (4, 5, 816 + 1, 1),         # 5 channels, tiles of 16-frame segments, one frame into the second tile
+    (3, 7, 20000, 3),           # 7 channels, ragged calls
     (40, 1, 4096, 1),           # mono Lines of half a tile of 32-frame segments: tiles of 16-frame segments
     (7, 2, 2048 + 600, 2),      # the same choice with ragged calls
 ])
 def test_tiled_form_matches_oracle_within_one_ulp(sections, lines, channels, frames, calls, monkeypatch):
-    """The LDS-tiled segmented form (1, 2, 4, 8 channels; one or two sections) on tile / segment boundaries; the
+    """The LDS-tiled segmented form (up to 8 channels; one or two sections) on tile / segment boundaries; the
     lane-walk form on the same input gives the same bits almost everywhere (same contract, other segment lengths)."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
     q = coeffs(3)[[0, 2]][:sections]   # the ringing section second
