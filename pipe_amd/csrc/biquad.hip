@@ -35,6 +35,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
+#include <atomic>
 
 #include <hip/hip_ext.h>
 
@@ -71,7 +73,7 @@ struct BiquadTransition {
     double m[2 * kMaxSegSections][2 * kMaxSegSections];
 };
 
-enum { kWhole = 0, kSegZeroState = 1, kSegFinal = 2 };
+enum { kWhole = 0, kSegZeroState = 1, kSegFinal = 2, kSegSingle = 3 };
 
 template <int NS>
 __device__ __forceinline__ double biquad_step(double x, double (&s1)[kMaxSections],
@@ -298,6 +300,50 @@ struct BiquadTilePowers {
     double m[kTilePowers][2 * kTileMaxSections][2 * kTileMaxSections];
 };
 
+// ---- one pass over the input (MODE kSegSingle): the tiles of a series chained by look-back -----------
+// A tile publishes its zero-start end state z_k as soon as its scan has it, then looks back: over the tiles
+// before it, adding P z_j and multiplying P by M^tile, until one of them has published its TRUE end state (or the
+// series' carried state is reached); that sum is the tile's start state, M^tile s + z_k its own true end state
+// (published for the tiles after it).  Every 64-bit word of a published state carries the launch's epoch in its
+// upper half (no flags, no fences, nothing to clear between launches).  Tiles take their index from their Line's
+// counter in the order they start, so a tile only ever waits for tiles that already run: no residency condition.
+// Segment g's start state is then its zero-start scan value + A^g s, A^g from a table.
+struct BiquadLookArgs {
+    unsigned long long *aggr, *incl;  // [T][nseries][2 S] doubles as two tagged words each
+    unsigned *ticket, *ticket_next;   // [nl] tiles started per Line: this launch's counters, the next launch's
+    const double *tab;                // [256][2 S][2 S]: A^g
+    double *state_out;                // the series' state after this call (copied over `state` after the launch)
+    int *err;                         // host-visible: a look-back that gave up
+    unsigned epoch;
+    int nl;
+};
+__device__ __forceinline__ void look_publish(unsigned long long *p, const double *v, int n, unsigned epoch)
+{
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v[i]);
+        __hip_atomic_store(p + 2 * i, ((unsigned long long)epoch << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 2 * i + 1, ((unsigned long long)epoch << 32) | (b >> 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int N>
+__device__ __forceinline__ bool look_read(const unsigned long long *p, double *v, unsigned epoch)
+{
+    unsigned long long w[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i)
+        w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i)
+        ok = ok && (unsigned)(w[i] >> 32) == epoch;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        v[i] = __builtin_bit_cast(double, (w[2 * i] & 0xffffffffull) | (w[2 * i + 1] << 32));
+    return ok;
+}
+
 template <typename T>
 struct TileVec;
 template <>
@@ -319,7 +365,8 @@ using TileStage = typename std::conditional<sizeof(TIn) == 4 && sizeof(TOut) == 
 template <typename TIn, typename TOut, int NS, bool GAIN, int MODE, int SEG>
 __global__ void __launch_bounds__(kTileThreads)
 biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, const BiquadArgs a, const BiquadCoeffs q,
-                   const BiquadTilePowers pw, int tiles_per_line, int C, int spc, int cmagic)
+                   const BiquadTilePowers pw, int tiles_per_line, int C, int spc, int cmagic, const BiquadLookArgs lk,
+                   const BiquadTransition mt)
 {
     constexpr int N = 2 * NS;
     constexpr int kTileSeg = SEG, kTileElems = kTileThreads * SEG, kSegLog = SEG == 32 ? 5 : 4;
@@ -328,11 +375,34 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     double *yb = reinterpret_cast<double *>(smem_raw);                 // [256][N]: the scan's exchange
     TS *xs = reinterpret_cast<TS *>(yb + kTileThreads * N);            // [256 segments][kTileSeg + 1]
     const int tid = (int)threadIdx.x;
-    const int line = (int)blockIdx.x / tiles_per_line;
-    const int tile = (int)blockIdx.x - line * tiles_per_line;
+    int line, tile;
+    if constexpr (MODE == kSegSingle) {  // in starting order, tile-major: the tile before mine started before me
+        if (tiles_per_line == 1) {  // (nobody to wait for: no need for an order)
+            tile = 0;
+            line = (int)blockIdx.x;
+        } else {
+            // a counter per Line (one counter for the launch: thousands of device-scope atomics on one address,
+            // 17 of 47 us); this launch's counters count up from zero, the tile that draws 0 clears the Line's
+            // counter of the NEXT launch (the two sets alternate)
+            line = (int)(blockIdx.x % (unsigned)lk.nl);
+            if (tid == 0) {
+                const int t = (int)__hip_atomic_fetch_add(lk.ticket + line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 0)
+                    lk.ticket_next[line] = 0u;
+                *reinterpret_cast<int *>(yb) = t;
+            }
+            __syncthreads();
+            tile = *reinterpret_cast<volatile int *>(yb);
+            __syncthreads();
+        }
+    } else {
+        line = (int)blockIdx.x / tiles_per_line;
+        tile = (int)blockIdx.x - line * tiles_per_line;
+    }
     // C channels (1 .. 8); spc = 256 / C segments per channel in a tile (lanes past C spc idle when C is not a power
     // of two); e / C for e < 9362 as (e cmagic) >> 16, cmagic = ceil(65536 / C)
     const int tfr = spc * kTileSeg;                                    // frames per tile
+    const int clog = C == 1 ? 0 : C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : -1;
     const int nelt = tfr * C;                                          // elements per tile (<= kTileElems)
     const int64_t f0 = (int64_t)tile * tfr;
     const int nreal = (int)(a.frames - f0 < tfr ? a.frames - f0 : tfr);  // frames of this tile inside the Line
@@ -359,14 +429,26 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 else
                     v[i] = V{};
             }
+            if (clog >= 0) {
+                // a power of two channels: chunk i of a lane sits i (256 VW / C / SEG) rows below chunk 0, element u of
+                // a chunk in channel u % C, frame u / C of it (no carries: VW divides SEG) -- one add per cell
+                const int b0 = cell(tid * VW);
+                const int di = ((kTileThreads * VW) >> clog >> kSegLog) * (kTileSeg + 1);
 #pragma unroll
-            for (int i = 0; i < NCH; ++i)
+                for (int i = 0; i < NCH; ++i)
 #pragma unroll
-                for (int u = 0; u < VW; ++u) {
-                    const int e = (tid + i * kTileThreads) * VW + u;
-                    if (e < nelt)
-                        xs[cell(e)] = (TS)v[i].v[u];
-                }
+                    for (int u = 0; u < VW; ++u)
+                        xs[b0 + i * di + (u & (C - 1)) * spc * (kTileSeg + 1) + (u >> clog)] = (TS)v[i].v[u];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) {
+                        const int e = (tid + i * kTileThreads) * VW + u;
+                        if (e < nelt)
+                            xs[cell(e)] = (TS)v[i].v[u];
+                    }
+            }
         } else {
             for (int e = tid; e < nelt; e += kTileThreads)
                 xs[cell(e)] = e < nel ? (TS)in[e] : (TS)0;
@@ -381,14 +463,24 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
     TS *__restrict__ col = xs + tid * (kTileSeg + 1);
     double s1[kMaxSections], s2[kMaxSections];
     auto walk = [&](bool write) {
+        if (nfr == kTileSeg) {  // (a whole segment: no test per frame)
 #pragma unroll
-        for (int i = 0; i < kTileSeg; ++i) {
-            if (i < nfr) {
+            for (int i = 0; i < kTileSeg; ++i) {
                 double y = biquad_step<NS>((double)col[i], s1, s2, q);
                 if (write) {
                     if constexpr (GAIN)
                         y = y * a.gain;
                     col[i] = (TS)y;  // (float32 staging only with float32 results: this is the result's rounding)
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < nfr; ++i) {
+                double y = biquad_step<NS>((double)col[i], s1, s2, q);
+                if (write) {
+                    if constexpr (GAIN)
+                        y = y * a.gain;
+                    col[i] = (TS)y;
                 }
             }
         }
@@ -448,6 +540,104 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
     for (int i = 0; i < N; ++i)
         st0[i] = g > 0 ? yb[(tid - 1) * N + i] : (MODE == kSegFinal ? tstate[i] : 0.0);
+    if constexpr (MODE == kSegSingle) {
+        double *pf = reinterpret_cast<double *>(xs + kTileThreads * (kTileSeg + 1));  // [8 channels][N]: the tiles' start states
+        if (active && g == 0) {
+            const int64_t slot = ((int64_t)tile * a.nseries + series) * (2 * N);
+            const bool full = nreal == tfr;
+            double zk[N], acc[N], P[N][N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                zk[i] = yb[(tid + spc - 1) * N + i];
+                acc[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    P[i][j] = i == j ? 1.0 : 0.0;
+            }
+            if (full && tile + 1 < tiles_per_line)
+                look_publish(lk.aggr + slot, zk, N, lk.epoch);
+            unsigned spins = 0;
+            for (int k = tile - 1;;) {
+                double v[N];
+                bool last = false, got = false;
+                if (k < 0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        v[i] = a.state[series * N + i];
+                    last = got = true;
+                } else {
+                    const int64_t sk = ((int64_t)k * a.nseries + series) * (2 * N);
+                    if (look_read<N>(lk.incl + sk, v, lk.epoch))
+                        last = got = true;
+                    else if (look_read<N>(lk.aggr + sk, v, lk.epoch))
+                        got = true;
+                }
+                if (got) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j)
+                            acc[i] = __builtin_fma(P[i][j], v[j], acc[i]);
+                    if (last)
+                        break;
+                    double Q[N][N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            double q2 = 0.0;
+#pragma unroll
+                            for (int l = 0; l < N; ++l)
+                                q2 = __builtin_fma(P[i][l], mt.m[l][j], q2);
+                            Q[i][j] = q2;
+                        }
+                    double pmax = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            P[i][j] = Q[i][j];
+                            pmax = __builtin_fmax(pmax, __builtin_fabs(Q[i][j]));
+                        }
+                    // what lies further back reaches this tile times less than 2^-70: below any rounding of the
+                    // state, so a long stream's tiles do not queue up behind each other (with one Line hundreds
+                    // of tiles run at once, none of them with its true end state yet)
+                    if (pmax < 0x1p-70)
+                        break;
+                    --k;
+                    spins = 0;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                        *lk.err = 1;
+                        break;
+                    }
+                }
+            }
+            if (full && tile + 1 < tiles_per_line) {
+                double e[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    e[i] = zk[i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        e[i] = __builtin_fma(mt.m[i][j], acc[j], e[i]);
+                }
+                look_publish(lk.incl + slot, e, N, lk.epoch);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                pf[c * N + i] = acc[i];
+        }
+        __syncthreads();
+        // segment g starts from its zero-start scan value + A^g (the tile's start state)
+        const double *__restrict__ tg = lk.tab + (int64_t)g * (N * N);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                st0[i] = __builtin_fma(tg[i * N + j], pf[c * N + j], st0[i]);
+    }
     if constexpr (MODE == kSegZeroState) {
         // the tile's zero-start end state: after the tile's last real frame.  A full last segment: its inclusive
         // value; a partial one: walked again from its start state (its own map is not A)
@@ -478,19 +668,37 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             s2[k] = st0[2 * k + 1];
         }
         walk(true);
+        if constexpr (MODE == kSegSingle) {
+            // the series' state after the call: with the lane that walked the Line's last frame
+            if (active && tile + 1 == tiles_per_line && g == ((nreal - 1) >> kSegLog)) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    lk.state_out[series * N + 2 * k] = s1[k];
+                    lk.state_out[series * N + 2 * k + 1] = s2[k];
+                }
+            }
+        }
         __syncthreads();
         TOut *__restrict__ out = out_base + ((int64_t)line * a.frames + f0) * C;
         using V = typename TileVec<TOut>::type;
         constexpr int VW = 16 / (int)sizeof(TOut), NCH = kTileElems / (kTileThreads * VW);
         if (nel % VW == 0) {
             V *__restrict__ vout = reinterpret_cast<V *>(out);
+            const int b0 = cell(tid * VW);
+            const int di = clog >= 0 ? ((kTileThreads * VW) >> clog >> kSegLog) * (kTileSeg + 1) : 0;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = tid + i * kTileThreads;
                 V v;
+                if (clog >= 0) {
 #pragma unroll
-                for (int u = 0; u < VW; ++u)
-                    v.v[u] = (TOut)xs[ch * VW + u < nelt ? cell(ch * VW + u) : 0];
+                    for (int u = 0; u < VW; ++u)
+                        v.v[u] = (TOut)xs[b0 + i * di + (u & (C - 1)) * spc * (kTileSeg + 1) + (u >> clog)];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < VW; ++u)
+                        v.v[u] = (TOut)xs[ch * VW + u < nelt ? cell(ch * VW + u) : 0];
+                }
                 if (ch * VW < nel)
                     vout[ch] = v;
             }
@@ -1023,9 +1231,22 @@ public:
         if (param != PIPE_HIP_PARAM_COEFFS || count != 5 * S_ || !values)
             return PIPE_HIP_EINVAL;
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
-        mfull_len_ = mlast_len_ = sp_len_ = -1;
+        mfull_len_ = mlast_len_ = sp_len_ = tab_seg_ = -1;
         kappa_ = -1.0;
         pw_seg_ = -1;
+        return PIPE_HIP_OK;
+    }
+    // Precondition as for the fused chain's: the stream of the last launch has been synchronised.
+    int poll_error() override
+    {
+        if (!err_.p || err_checked_)
+            return PIPE_HIP_OK;
+        volatile int *e = static_cast<volatile int *>(err_.p);
+        err_checked_ = true;
+        if (*e != 0) {
+            *e = 0;
+            return PIPE_HIP_EHIP;
+        }
         return PIPE_HIP_OK;
     }
     // a gain stage that directly follows this biquad in a chain is folded into the
@@ -1081,7 +1302,7 @@ public:
         const int tc = cfg.channels, tspc = tc <= 8 ? kTileThreads / tc : 0;
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
                            frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
-                           !(cfg.channels >= kTileWalkChannels && nl >= kTileWalkLines && segmented);  // (many Lines of many channels: the lane walk)
+                           !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
         PH_TRY(timer.begin(s));
         if (tiled) {
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
@@ -1091,10 +1312,6 @@ public:
             const int tfr = (int)(seg == 32 ? t32 : t16);
             a.T = (int)((frames + tfr - 1) / tfr);
             a.seglen = tfr;
-            const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
-            if (seg_.bytes < need)
-                PH_TRY(seg_.alloc(need));
-            a.seg = static_cast<double *>(seg_.p);
             if (mfull_len_ != tfr) {
                 transition(tfr, &mfull_);
                 mfull_len_ = tfr;
@@ -1118,10 +1335,29 @@ public:
                 mlast_len_ = last_len;
             }
             const dim3 tgrid((unsigned)a.T * (unsigned)nl);
-            const size_t lds_rest = sizeof(double) * (size_t)kTileThreads * 2u * (size_t)S_;
+            const size_t lds_rest = sizeof(double) * ((size_t)kTileThreads * 2u * (size_t)S_ + 8u * 2u * (size_t)S_);
+            const int cmagic = (65536 + tc - 1) / tc;
+            const bool single = !std::getenv("PIPE_HIP_BIQUAD_TWO_PASS");
+            BiquadLookArgs lk{};
+            if (single) {
+                PH_TRY(prepare_look(&lk, a, seg, nl, tgrid.x, s));
+            } else {
+                const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
+                if (seg_.bytes < need)
+                    PH_TRY(seg_.alloc(need));
+                a.seg = static_cast<double *>(seg_.p);
+            }
 #define PH_BT4(TI, TO, NSV, G, SEGV)                                                                                       \
     do {                                                                                                              \
         const size_t lds = lds_rest + sizeof(TileStage<TI, TO>) * (size_t)kTileThreads * (SEGV + 1);                 \
+        if (single) {                                                                                                 \
+            auto k0 = biquad_tile_kernel<TI, TO, NSV, G, kSegSingle, SEGV>;                                           \
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds));                                                                    \
+            hipLaunchKernelGGL(k0, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                  \
+                               static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, cmagic, lk, mfull_);              \
+            break;                                                                                                    \
+        }                                                                                                             \
         auto k1 = biquad_tile_kernel<TI, TO, NSV, G, kSegZeroState, SEGV>;                                            \
         auto k2 = biquad_tile_kernel<TI, TO, NSV, G, kSegFinal, SEGV>;                                                \
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize,    \
@@ -1129,13 +1365,13 @@ public:
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                    (int)lds));                                                                        \
         hipLaunchKernelGGL(k1, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
-                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, (65536 + tc - 1) / tc);                                          \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, cmagic, lk, mfull_);                  \
         if (a.T > kWaveScanMinTiles && !std::getenv("PIPE_HIP_BIQUAD_NO_WAVE_SCAN"))                                \
             launch_scan_wave(s, a);                                                                                   \
         else                                                                                                          \
             launch_scan(sblocks, s, a, mlast_);                                                                       \
         hipLaunchKernelGGL(k2, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
-                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, (65536 + tc - 1) / tc);                                          \
+                           static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, cmagic, lk, mfull_);                  \
     } while (0)
 #define PH_BT3(TI, TO, NSV, G)                 \
     do {                                       \
@@ -1170,6 +1406,9 @@ public:
 #undef PH_BT
 #undef PH_BT3
 #undef PH_BT4
+            if (single)  // the series' new state over the old one (tiles of this launch read the old one at any time)
+                PH_HIP(hipMemcpyAsync(a.state, lk.state_out, sizeof(double) * (size_t)a.nseries * 2u * (size_t)S_,
+                                      hipMemcpyDeviceToDevice, s));
         } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
@@ -1476,9 +1715,84 @@ public:
         }
     }
 
+    // (tile form, one pass) scratch for the look-back, the table A^g, the launch's epoch
+    int prepare_look(BiquadLookArgs *lk, const BiquadArgs &a, int seg, int nl, unsigned grid, hipStream_t s)
+    {
+        const int n = 2 * S_;
+        const size_t words = (size_t)a.T * (size_t)a.nseries * 2u * (size_t)n;  // per array
+        const size_t off_state = 2 * words * sizeof(unsigned long long);
+        const size_t need = off_state + sizeof(double) * (size_t)a.nseries * n;
+        if (look_.bytes < need) {
+            PH_TRY(look_.alloc(need + need / 2));
+            PH_HIP(hipMemsetAsync(look_.p, 0, look_.bytes, s));  // (tags of a previous owner of the memory)
+        }
+        if (!err_.p) {
+            PH_TRY(err_.alloc(sizeof(int)));
+            *static_cast<volatile int *>(err_.p) = 0;
+            void *alias = nullptr;
+            PH_HIP(hipHostGetDevicePointer(&alias, err_.p, 0));
+            err_dev_ = static_cast<int *>(alias);
+        }
+        // two sets of per-Line counters, used in turn; a launch over other Lines than the last one starts from
+        // cleared sets (the tile that clears a Line's next counter only runs in launches that cover the Line)
+        const size_t tick_bytes = sizeof(unsigned) * 2u * (size_t)cfg.lines;
+        if (!ticket_.p || tick_first_ != win_first || tick_nl_ != nl) {
+            if (!ticket_.p)
+                PH_TRY(ticket_.alloc(tick_bytes));
+            PH_HIP(hipMemsetAsync(ticket_.p, 0, tick_bytes, s));
+            tick_first_ = win_first;
+            tick_nl_ = nl;
+        }
+        if (a.T > 1)  // (a launch of one-tile Lines draws no numbers and clears nothing)
+            tick_set_ ^= 1;
+        if (tab_seg_ != seg) {
+            BiquadTransition ma;
+            transition(seg, &ma);
+            tab_host_.assign((size_t)kTileThreads * n * n, 0.0);
+            long double p[2 * kTileMaxSections][2 * kTileMaxSections], t[2 * kTileMaxSections][2 * kTileMaxSections];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    p[i][j] = i == j ? 1.0L : 0.0L;
+            for (int g = 0; g < kTileThreads; ++g) {
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j)
+                        tab_host_[((size_t)g * n + i) * n + j] = (double)p[i][j];
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        long double acc = 0.0L;
+                        for (int l = 0; l < n; ++l)
+                            acc += (long double)ma.m[i][l] * p[l][j];
+                        t[i][j] = acc;
+                    }
+                std::memcpy(p, t, sizeof p);
+            }
+            if (!tab_.p)
+                PH_TRY(tab_.alloc(sizeof(double) * (size_t)kTileThreads * 16u));
+            PH_HIP(hipMemcpyAsync(tab_.p, tab_host_.data(), sizeof(double) * tab_host_.size(), hipMemcpyHostToDevice, s));
+            tab_seg_ = seg;
+        }
+        static std::atomic<unsigned> epochs{0};
+        unsigned e = ++epochs;
+        if (e == 0)
+            e = ++epochs;
+        lk->aggr = static_cast<unsigned long long *>(look_.p);
+        lk->incl = lk->aggr + words;
+        lk->state_out = reinterpret_cast<double *>(static_cast<char *>(look_.p) + off_state);
+        lk->ticket = static_cast<unsigned *>(ticket_.p) + (size_t)tick_set_ * cfg.lines + win_first;
+        lk->ticket_next = static_cast<unsigned *>(ticket_.p) + (size_t)(tick_set_ ^ 1) * cfg.lines + win_first;
+        lk->tab = static_cast<const double *>(tab_.p);
+        lk->err = err_dev_;
+        lk->epoch = e;
+        lk->nl = nl;
+        err_checked_ = false;
+        return PIPE_HIP_OK;
+    }
+
     // (tile form, many tiles) one wave per series; the table (M^R)^(2^j) by squaring in long double
     static constexpr int kWaveScanMinTiles = 32;
-    static constexpr int kTileWalkLines = 256, kTileWalkChannels = 6;  // (512 Lines x 6 ch: 250 against 224; x 8 ch: 404 against 338; 1024 x 3 ch: 192 against 214)
+    // (A/B: PIPE_HIP_BIQUAD_TILE_WALK_LINES=n sends n or more Lines of 6+ channels to the lane walk, the rule before the
+    // one-pass tile kernel: 512 x 8 ch 402 against 500, 4096 x 8 ch 355 against 625)
+    static constexpr int kTileWalkLines = 1 << 30, kTileWalkChannels = 6;
     void launch_scan_wave(hipStream_t s, const BiquadArgs &a)
     {
         const int R = (a.T + 63) / 64, n = 2 * S_;
@@ -1562,11 +1876,19 @@ private:
     const int64_t tile_min_frames_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES"))
                                          : 4 * kChunk;
+    const int tile_walk_lines_ = std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES") ? std::atoi(std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES")) : kTileWalkLines;
     BiquadTransition mfull_{}, mlast_{};
     int mfull_len_ = -1, mlast_len_ = -1;  // (the lane-walk form computes its own last-segment matrix per call)
     BiquadTilePowers pw_{};
     int pw_seg_ = -1;
     double kappa_ = -1.0;
+    DevBuf look_, ticket_, tab_;
+    PinnedBuf err_;
+    int *err_dev_ = nullptr;
+    bool err_checked_ = true;
+    int tick_set_ = 0, tick_first_ = -1, tick_nl_ = -1;
+    std::vector<double> tab_host_;
+    int tab_seg_ = -1;
     BiquadScanPowers sp_{};
     int sp_len_ = -1, sp_R_ = -1;
 };

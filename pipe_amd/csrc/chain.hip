@@ -132,7 +132,15 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
-    int poll_error() override { return fused_ ? fused_->poll_error() : PIPE_HIP_OK; }
+    int poll_error() override
+    {
+        int rc = fused_ ? fused_->poll_error() : PIPE_HIP_OK;
+        for (auto &st : stages) {
+            const int r = st->poll_error();
+            rc = rc != PIPE_HIP_OK ? rc : r;
+        }
+        return rc;
+    }
     int set_stage_param(int32_t stage, int32_t param, const double *values, int32_t count) override
     {
         if (stage < 0 || (size_t)stage >= stages.size())

@@ -16,7 +16,7 @@ st = torch.cuda.Stream()
 S = int(os.environ.get("PROBE_SECTIONS", "1"))
 q = np.vstack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(fc=4000.0, q=1.3)][:S])
 for lines, C, K in ((4096, 1, 1), (2048, 2, 1), (512, 8, 1), (64, 2, 32), (8, 2, 256), (1, 2, 2048), (64, 1, 64), (1, 1, 4096), (1, 8, 512),
-                     (1024, 3, 1), (4, 3, 256), (512, 6, 1), (2, 6, 256), (1, 5, 512)):
+                     (1024, 3, 1), (4, 3, 256), (512, 6, 1), (2, 6, 256), (1, 5, 512), (2048, 8, 1), (4096, 8, 1), (128, 8, 4), (256, 7, 2), (4096, 6, 1)):
     n = lines * K * F * C
     if os.environ.get("PROBE_ONLY_C") and str(C) not in os.environ["PROBE_ONLY_C"].split(","):
         continue
