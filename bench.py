@@ -518,6 +518,24 @@ def run_rank(args, rank, world, local, sync, launch):
             }
             del do
 
+        # the biquad stage alone (no BASELINE config of its own; configs[3] runs it fused): the time-segmented
+        # form through LDS tiles, one pass, on the configs[3] shape and on ONE stereo Line of the same sample count
+        bq = {}
+        for tag, (Lb, Cb, Kb) in (("lines_512x8", (512, 8, 1)), ("one_stereo_line", (1, 2, 2048))):
+            nb = Lb * Kb * F * Cb
+            with P.Biquad(synth.biquad_rbj_lowpass(), F, Cb, dtype=np_dtype, device=local, lines=Lb, max_batch=Kb) as bqp:
+                bqp.start()
+                di = own_input(nb, 0)
+                do = torch.empty_like(di)
+                _, kmsb, nlb, knb = timed(bqp, 200, 300, di, do, Kb * F)
+                msb = kmsb / max(nlb, 1)
+                bq[tag] = {"workload": f"{Lb} Lines x {Cb} ch x {Kb} buffers of {F} frames, 1 section", "kernel": knb,
+                           "avg_ms": round(msb, 5), "msamples_per_s": round(nb / (msb * 1e-3) / 1e6, 1),
+                           "algorithmic_bytes_per_launch": nb * bps,
+                           "roofline_frac": round(nb * bps / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                del do
+        result["biquad_alone"] = bq
+
         # BASELINE configs[4]: the 44.1 -> 48 kHz polyphase resampler (160/147, 24 taps per phase) over
         # 1024 consecutive 4096 x 2 buffers per launch, and the 2-input mix ("merger fan-in": the
         # build-defined sum) over a stream of the resampler's output size

@@ -54,6 +54,11 @@ def test_default_line_has_every_contract_field():
     assert r5["out_frames"] in (-(-1024 * 4096 * 160 // 147), 1024 * 4096 * 160 // 147)
     assert r5["algorithmic_bytes_per_launch"] == (r5["in_frames"] + r5["out_frames"]) * 2 * 4
     assert c5["mix"]["kernel"] == "mix_kernel<f32>" and 0 < c5["mix"]["roofline_frac"] < 1.0
+    # the biquad stage alone: the one-pass LDS-tile form, on the configs[3] shape and on one long stereo Line
+    for tag in ("lines_512x8", "one_stereo_line"):
+        b = d["biquad_alone"][tag]
+        assert b["kernel"].startswith("biquad_tile_kernel") and b["algorithmic_bytes_per_launch"] == 8 * 512 * 4096 * 8
+        assert 0 < b["roofline_frac"] < 1.0
 
 
 def test_config3_line_names_the_fused_chain():
