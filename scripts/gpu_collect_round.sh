@@ -55,6 +55,12 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print(json.dumps({'channels': $c, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg_kernel_ms'], 'hbm_frac': r['frac'], 'gsamples_per_s': round(d['value']/1e3,1)}))" >> $OUT/channels.jsonl
 done
 python scripts/fir_exact_sweep.py > $OUT/fir_exact_sweep.txt 2>&1
+# the segmented biquad over shapes: one-pass tile form, 1 and 2 sections; two-pass tiles and the lane walk beside it
+( for sct in 1 2; do echo "== sections $sct"; PROBE_SECTIONS=$sct python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu; done
+  echo "== two passes + scan kernel (PIPE_HIP_BIQUAD_TWO_PASS)"; PIPE_HIP_BIQUAD_TWO_PASS=1 python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu
+  echo "== lane walk (PIPE_HIP_BIQUAD_NO_TILE)"; PIPE_HIP_BIQUAD_NO_TILE=1 python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu ) > $OUT/biquad_shapes.txt
+( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && PROBE_ONLY_C=2,8 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bqprof -o bq -- python scripts/biquad_shapes_probe.py ) < /dev/null > /dev/null 2>&1
+cp $OUT/bqprof/bq_kernel_stats.csv $OUT/biquad_tile_kernel_stats.csv 2>/dev/null; rm -rf $OUT/bqprof
 SEC=3 bash scripts/gpu_energy_table.sh > $OUT/energy.log 2>&1
 cp gpurun_out/energy/table.txt $OUT/energy_table.txt
 grep -v amdgpu $OUT/chain_probe.txt; cat $OUT/long_fir.jsonl; tail -4 $OUT/hostcall.jsonl; tail -12 $OUT/energy_table.txt
