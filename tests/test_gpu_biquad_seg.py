@@ -133,6 +133,7 @@ def test_tiled_form_matches_oracle_within_one_ulp(sections, lines, channels, fra
     """The LDS-tiled segmented form (up to 8 channels; one or two sections) on tile / segment boundaries; the
     lane-walk form on the same input gives the same bits almost everywhere (same contract, other segment lengths)."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
+    monkeypatch.setenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES", "1")   # (shipped: 512 frames a call, below that the lane walk)
     q = coeffs(3)[[0, 2]][:sections]   # the ringing section second
     x = np.stack([synth.samples(synth.line_seed(90 + l), 0, frames * channels, np.float32).reshape(frames, channels)
                   for l in range(lines)])
@@ -207,6 +208,19 @@ def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact
     got, name = run(q, x, lines, 2, exact=False)
     assert "segmented" not in name, name
     assert np.array_equal(got, oracle(q, x).astype(np.float32))
+
+
+def test_calls_shorter_than_512_frames_keep_the_lane_walk(monkeypatch):
+    """The shipped threshold: Lines of fewer than 512 frames a call would leave the tiles mostly empty."""
+    monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
+    q = coeffs(1)
+    for frames, form in ((511, "biquad_kernel"), (512, "biquad_tile_kernel")):
+        x = np.stack([synth.samples(synth.line_seed(500 + l), 0, frames * 2, np.float32).reshape(frames, 2) for l in range(64)])
+        got, name = run(q, x, 64, 1, exact=False)
+        assert form in name and "segmented" in name, name
+        want = oracle(q, x).astype(np.float32)
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        assert np.all(d <= relaxed_ulp(q, want))
 
 
 def test_float64_buffers_never_take_the_segmented_form(monkeypatch):
