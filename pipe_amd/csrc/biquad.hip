@@ -1308,7 +1308,9 @@ public:
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
             const int64_t t32 = tspc * 32, t16 = tspc * 16;
             const int64_t waste32 = (frames + t32 - 1) / t32 * t32 - frames, waste16 = (frames + t16 - 1) / t16 * t16 - frames;
-            const int seg = waste32 - waste16 > frames / 4 && !std::getenv("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32;
+            const char *seg_env = std::getenv("PIPE_HIP_BIQUAD_TILE_SEG");  // A/B: 16 or 32 whatever the shape
+            const int seg = seg_env ? (std::atoi(seg_env) == 16 ? 16 : 32)
+                                    : (waste32 - waste16 > frames / 4 && !std::getenv("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32);
             const int tfr = (int)(seg == 32 ? t32 : t16);
             a.T = (int)((frames + tfr - 1) / tfr);
             a.seglen = tfr;

@@ -24,7 +24,11 @@ for lines, C, K in [tuple(int(v) for v in t.split(",")) for t in SHAPES.split(";
     d_in = torch.empty(n, dtype=torch.float32, device="cuda")
     P.synth_fill(d_in, synth.line_seed(0))
     d_out = torch.empty_like(d_in)
-    with P.Biquad(q, F, C, dtype=np.float32, lines=lines, max_batch=K) as p:
+    kw = dict(dtype=np.float32, lines=lines, max_batch=K)
+    # PROBE_CHAIN=gb: gain -> biquad as a staged chain (the biquad reads float64, as behind an overlap-save FIR)
+    mk = (lambda: P.Chain([P.Gain(1.0, F, C, **kw), P.Biquad(q, F, C, **kw)])) if os.environ.get("PROBE_CHAIN") == "gb" \
+        else (lambda: P.Biquad(q, F, C, **kw))
+    with mk() as p:
         p.start()
         for _ in range(10):
             p.process_batch(d_in, d_out, K * F, stream=st.cuda_stream)
