@@ -35,6 +35,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <cstring>
+#include <memory>
 #include <vector>
 #include <atomic>
 
@@ -1233,12 +1235,17 @@ public:
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
         mfull_len_ = mlast_len_ = sp_len_ = tab_seg_ = -1;
         kappa_ = -1.0;
+        half_[0].reset();
+        half_[1].reset();
         pw_seg_ = -1;
         return PIPE_HIP_OK;
     }
     // Precondition as for the fused chain's: the stream of the last launch has been synchronised.
     int poll_error() override
     {
+        for (auto &h : half_)
+            if (h && h->poll_error() != PIPE_HIP_OK)
+                return PIPE_HIP_EHIP;
         if (!err_.p || err_checked_)
             return PIPE_HIP_OK;
         volatile int *e = static_cast<volatile int *>(err_.p);
@@ -1303,6 +1310,11 @@ public:
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
                            frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
+        // 3 or 4 sections: the tile kernel holds two, so two tile passes over the halves of the cascade with a float64
+        // stream between them (24 bytes a sample instead of 8) -- where the lane walk crawls (few Lines or channels)
+        if (relaxed && S_ > kTileMaxSections && S_ <= 2 * kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
+            frames >= tile_min_frames_ && split_wanted(nl))
+            return run_split(d_in, in_dtype, d_out, out_dtype, frames, a, s);
         PH_TRY(timer.begin(s));
         if (tiled) {
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
@@ -1717,6 +1729,52 @@ public:
         }
     }
 
+    // (3 - 4 sections through the tile kernel) the halves of the cascade as two handles of their own: their states are
+    // slices of this handle's state array, copied in before and out after the two passes, so every other form (and
+    // the next call, whatever form it takes) finds the state where it always is
+    bool split_wanted(int nl) const
+    {
+        if (std::getenv("PIPE_HIP_BIQUAD_NO_SPLIT"))
+            return false;
+        const char *e = std::getenv("PIPE_HIP_BIQUAD_SPLIT_MAX_SERIES");
+        return (int64_t)nl * cfg.channels <= (e ? std::atoll(e) : kSplitMaxSeries);
+    }
+    int run_split(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames, const BiquadArgs &a, hipStream_t s)
+    {
+        const int sa = kTileMaxSections, sb = S_ - kTileMaxSections, n = 2 * S_;
+        if (!half_[0]) {
+            for (int h = 0; h < 2; ++h) {
+                auto c = std::make_unique<Biquad>();
+                PH_TRY(c->init_common(&cfg));
+                PH_TRY(c->init(&q_.c[h ? sa : 0][0], h ? sb : sa));
+                c->seg_min_samples_ = 1;  // (this handle decided)
+                half_[h] = std::move(c);
+            }
+        }
+        const size_t need = sizeof(double) * (size_t)frames * (size_t)a.nseries;
+        if (mid_.bytes < need)
+            PH_TRY(mid_.alloc(need));
+        PH_TRY(timer.begin(s));
+        const size_t row = sizeof(double) * (size_t)n, wa = sizeof(double) * 2u * (size_t)sa, wb = sizeof(double) * 2u * (size_t)sb;
+        double *sta = static_cast<double *>(half_[0]->state_.p) + (size_t)win_first * cfg.channels * 2u * sa;
+        double *stb = static_cast<double *>(half_[1]->state_.p) + (size_t)win_first * cfg.channels * 2u * sb;
+        PH_HIP(hipMemcpy2DAsync(sta, wa, a.state, row, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        PH_HIP(hipMemcpy2DAsync(stb, wb, a.state + 2 * sa, row, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        for (int h = 0; h < 2; ++h)
+            half_[h]->set_window(win_first, win_count);
+        half_[0]->relaxed_f64_out = true;
+        half_[1]->relaxed_f64_out = relaxed_f64_out;
+        half_[1]->set_post_gain(has_gain_, gain_);
+        PH_TRY(half_[0]->run(d_in, in_dtype, mid_.p, PIPE_HIP_F64, frames, s));
+        PH_TRY(half_[1]->run(mid_.p, PIPE_HIP_F64, d_out, out_dtype, frames, s));
+        PH_HIP(hipMemcpy2DAsync(a.state, row, sta, wa, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        PH_HIP(hipMemcpy2DAsync(a.state + 2 * sa, row, stb, wb, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        PH_TRY(timer.end(s));
+        const bool tiles = std::strstr(half_[0]->last_kernel, "biquad_tile_kernel") && std::strstr(half_[1]->last_kernel, "biquad_tile_kernel");
+        last_kernel = tiles ? "biquad_tile_kernel<segmented, two halves of the cascade>" : "biquad_kernel<segmented, two halves of the cascade>";
+        return PIPE_HIP_OK;
+    }
+
     // (tile form, one pass) scratch for the look-back, the table A^g, the launch's epoch
     int prepare_look(BiquadLookArgs *lk, const BiquadArgs &a, int seg, int nl, unsigned grid, hipStream_t s)
     {
@@ -1872,7 +1930,7 @@ private:
     size_t state_bytes_ = 0;
     bool exact_ = false;
     const bool env_exact_ = std::getenv("PIPE_HIP_BIQUAD_EXACT") != nullptr;
-    const int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
+    int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))
                                          : (int64_t)1 << 20;
     const int64_t tile_min_frames_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
@@ -1884,6 +1942,11 @@ private:
     BiquadTilePowers pw_{};
     int pw_seg_ = -1;
     double kappa_ = -1.0;
+    std::unique_ptr<Biquad> half_[2];
+    DevBuf mid_;
+    // (3 sections, 16.7 M samples: 1 Line x 2 ch 113 Gsamples/s against the lane walk's 12, 64 x 2 ch 120 against 48,
+    // 2048 x 2 ch even; 512 x 8 ch 127 against 218)
+    static constexpr int64_t kSplitMaxSeries = 2048;
     DevBuf look_, ticket_, tab_;
     PinnedBuf err_;
     int *err_dev_ = nullptr;

@@ -14,7 +14,8 @@ from pipe_amd import processors as P, synth  # noqa: E402
 F = int(os.environ.get("PROBE_F", "4096"))   # frames per buffer
 st = torch.cuda.Stream()
 S = int(os.environ.get("PROBE_SECTIONS", "1"))
-q = np.vstack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(fc=4000.0, q=1.3)][:S])
+q = np.vstack([synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(fc=4000.0, q=1.3), synth.biquad_rbj_lowpass(fc=300.0, q=4.0),
+               synth.biquad_rbj_lowpass(fc=2500.0, q=0.9)][:S])
 SHAPES = os.environ.get("PROBE_SHAPES")   # "lines,channels,buffers;..." instead of the list below
 for lines, C, K in [tuple(int(v) for v in t.split(",")) for t in SHAPES.split(";")] if SHAPES else ((4096, 1, 1), (2048, 2, 1), (512, 8, 1), (64, 2, 32), (8, 2, 256), (1, 2, 2048), (64, 1, 64), (1, 1, 4096), (1, 8, 512),
                      (1024, 3, 1), (4, 3, 256), (512, 6, 1), (2, 6, 256), (1, 5, 512), (2048, 8, 1), (4096, 8, 1), (128, 8, 4), (256, 7, 2), (4096, 6, 1)):

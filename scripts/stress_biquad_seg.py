@@ -25,7 +25,7 @@ kinds, worst = {}, 0.0
 for it in range(iters):
     C = int(rng.choice([1, 2, 4, 8, 2, 1, 3, 6, 5, 7, 9, 12]))
     lines = int(rng.choice([1, 1, 2, 5, 37, 300]))
-    S = int(rng.choice([1, 2, 2, 3]))
+    S = int(rng.choice([1, 2, 2, 3, 4, 5]))
     q = np.vstack([synth.biquad_rbj_lowpass(fc=float(np.exp(rng.uniform(np.log(60.0), np.log(12000.0)))),
                                             q=float(rng.uniform(0.5, 6.0))) for _ in range(S)])
     k = kappa(q)
@@ -37,7 +37,8 @@ for it in range(iters):
     total = sum(calls)
     shape = str(rng.choice(["b", "b", "bg", "gb", "bgg"]))
     inplace = shape == "b" and rng.random() < 0.3
-    for knob in ("PIPE_HIP_BIQUAD_NO_TILE", "PIPE_HIP_BIQUAD_NO_WAVE_SCAN", "PIPE_HIP_BIQUAD_TILE_SEG32"):
+    for knob in ("PIPE_HIP_BIQUAD_NO_TILE", "PIPE_HIP_BIQUAD_NO_WAVE_SCAN", "PIPE_HIP_BIQUAD_TILE_SEG32", "PIPE_HIP_BIQUAD_TWO_PASS",
+                 "PIPE_HIP_BIQUAD_NO_SPLIT"):
         os.environ.pop(knob, None)
         if rng.random() < 0.2:
             os.environ[knob] = "1"
@@ -55,7 +56,7 @@ for it in range(iters):
             d_out = d_in if inplace else torch.full_like(d_in, float("nan"))
             p.process_batch(d_in, d_out, n)
             torch.cuda.synchronize()
-            nm = p.kernel_name().split("<")[0] + ("/seg" if "segmented" in p.kernel_name() else "")
+            nm = p.kernel_name().split("<")[0] + ("/seg" if "segmented" in p.kernel_name() else "") + ("/halves" if "two halves" in p.kernel_name() else "")
             kinds[nm] = kinds.get(nm, 0) + 1
             outs.append(d_out.cpu().numpy())
             pos += n

@@ -210,6 +210,42 @@ def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact
     assert np.array_equal(got, oracle(q, x).astype(np.float32))
 
 
+@pytest.mark.parametrize("sections", [3, 4])
+@pytest.mark.parametrize("lines,channels", [(1, 2), (3, 1), (2, 5), (40, 8)])
+def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channels, monkeypatch):
+    """The tile kernel holds two sections: a cascade of 3 or 4 runs as its two halves, a float64 stream between
+    them, the halves' states slices of the handle's own -- so a short call in the ordered form right after a
+    long one (and a long one after that) continue the same state."""
+    monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
+    q = np.vstack([coeffs(3), synth.biquad_rbj_lowpass(fc=2500.0, q=0.9)])[[0, 2, 1, 3]][:sections]
+    calls = [4096 * 3 + 5, 50, 2048 + 700]
+    total = sum(calls)
+    x = np.stack([synth.samples(synth.line_seed(700 + l), 0, total * channels, np.float32).reshape(total, channels)
+                  for l in range(lines)])
+    names, outs, pos = [], [], 0
+    with P.Biquad(q, max(calls), channels, dtype=np.float32, lines=lines, max_batch=1) as p:
+        p.start()
+        for n in calls:
+            xin = torch.from_numpy(np.ascontiguousarray(x[:, pos:pos + n, :])).cuda()
+            y = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, y, n)
+            torch.cuda.synchronize()
+            names.append(p.kernel_name())
+            outs.append(y.cpu().numpy())
+            pos += n
+    assert "two halves" in names[0] and "biquad_tile_kernel" in names[0] and "two halves" in names[2], names
+    assert "segmented" not in names[1], names
+    got = np.concatenate(outs, axis=1)
+    want = oracle(q, x).astype(np.float32)
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert np.all(d <= relaxed_ulp(q, want)), float((d / relaxed_ulp(q, want)).max())
+    assert np.count_nonzero(got != want) <= max(4, got.size // 50000)
+    monkeypatch.setenv("PIPE_HIP_BIQUAD_NO_SPLIT", "1")
+    walk, name = run(q, x, lines, 1, exact=False)
+    assert "two halves" not in name and "segmented" in name
+    assert np.count_nonzero(walk != got) <= max(8, got.size // 25000)
+
+
 def test_calls_shorter_than_512_frames_keep_the_lane_walk(monkeypatch):
     """The shipped threshold: Lines of fewer than 512 frames a call would leave the tiles mostly empty."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
