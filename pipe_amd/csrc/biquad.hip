@@ -280,7 +280,7 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
     }
 }
 
-// ---- time-segmented form through LDS tiles (few channels) -------------------------------------------
+// ---- time-segmented form through LDS tiles (up to 8 channels) ---------------------------------------
 // The kernels above give every lane ONE series and let it walk its frames in place: with many channels per
 // frame neighbouring lanes share cache lines (8 channels, 512 Lines: 400 Gsamples/s), with one or two each lane
 // drags its own line along (74 / 166 Gsamples/s; one long stereo stream: 22).  Here a workgroup takes a TILE of
@@ -288,11 +288,14 @@ biquad_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, cons
 // a lane, all of the tile's loads in flight at once), lane (c, g) walks segment g -- SEG frames -- of channel c out
 // of LDS (segments SEG + 1 apart: the lanes on different banks), the 256 / C segments of a channel are chained by
 // a scan inside the workgroup (affine maps with one constant matrix: y_g = A y_{g-1} + z_g, Hillis-Steele with
-// A^(2^k) from a table), and the tiles of a series by the same three passes as above: pass 1 writes a tile's
-// zero-start end state, a scan kernel turns those into the tiles' start states, pass 2 folds the tile's start state
-// into segment 0, scans, walks every segment from its true start state and stores the tile coalesced.  Same
-// arithmetic contract as the lane-walk form (start states through powers of the transition matrix).
-// 280-340 Gsamples/s from 4096 Lines of one buffer to ONE Line of 4096 buffers (scripts/biquad_shapes_probe.py).
+// A^(2^k) from a table).  The tiles of a series are chained
+//   * in ONE pass (MODE kSegSingle, what ships): by look-back between the tiles of the launch, see BiquadLookArgs;
+//   * or (PIPE_HIP_BIQUAD_TWO_PASS, the A/B form) by the same three passes as above: pass 1 (kSegZeroState) writes a
+//     tile's zero-start end state, a scan kernel turns those into the tiles' start states, pass 2 (kSegFinal) folds
+//     the tile's start state into segment 0, scans, walks every segment from its true start state.
+// The tile is stored coalesced.  Same arithmetic contract as the lane-walk form (start states through powers of
+// the transition matrix).  16.7 M samples a call, one pass: 528 Gsamples/s over 2048 stereo Lines of one buffer,
+// 362 over ONE Line of 2048 buffers (scripts/biquad_shapes_probe.py; two passes: 350 / 308).
 constexpr int kTileThreads = 256;
 // frames per segment: SEG = 32, or 16 where Lines are short against a tile of 32s (4096-frame mono Lines would
 // leave half of every 8192-frame tile empty)
