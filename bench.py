@@ -133,6 +133,7 @@ PMC_KERNELS = {
     "main_chain": r"fir_ols32_kernel<float, float, [12]",
     "c4_chain": r"fir_ols32_kernel<float, float, [12]",
     "c5_resampler": r"resample_(pair|tiled)_kernel<",
+    "biquad_alone": r"biquad_tile_kernel<float, float, 1, false, 3",
 }
 
 
@@ -587,6 +588,8 @@ def run_rank(args, rank, world, local, sync, launch):
             want["c4_chain"] = (PMC_KERNELS["c4_chain"], result["c4_chain"]["algorithmic_bytes_per_launch"])
         if "c5_resampler_mix" in result:
             want["c5_resampler"] = (PMC_KERNELS["c5_resampler"], result["c5_resampler_mix"]["resampler"]["algorithmic_bytes_per_launch"])
+        if "biquad_alone" in result:  # (both shapes run this kernel over the same byte count)
+            want["biquad_alone"] = (PMC_KERNELS["biquad_alone"], result["biquad_alone"]["lines_512x8"]["algorithmic_bytes_per_launch"])
         t_pmc = time.perf_counter()
         live = live_pmc(args, want) if want else {}
         src_live = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x 2 + WRITE_SIZE)"
@@ -599,6 +602,9 @@ def run_rank(args, rank, world, local, sync, launch):
         if live.get("c5_resampler"):
             result["c5_resampler_mix"]["resampler"]["traffic"] = live["c5_resampler"]
             result["c5_resampler_mix"]["resampler"]["traffic_source"] = src_live
+        if live.get("biquad_alone"):
+            result["biquad_alone"]["traffic"] = live["biquad_alone"]  # mean over the two shapes' launches
+            result["biquad_alone"]["traffic_source"] = src_live
         result["roofline"]["pmc_passes_s"] = round(time.perf_counter() - t_pmc, 1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

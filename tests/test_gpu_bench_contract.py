@@ -59,6 +59,8 @@ def test_default_line_has_every_contract_field():
         b = d["biquad_alone"][tag]
         assert b["kernel"].startswith("biquad_tile_kernel") and b["algorithmic_bytes_per_launch"] == 8 * 512 * 4096 * 8
         assert 0 < b["roofline_frac"] < 1.0
+    tb = d["biquad_alone"].get("traffic")   # (live PMC passes; absent without rocprofv3)
+    assert tb is None or 1.0 <= tb / (8 * 512 * 4096 * 8) < 1.2
 
 
 def test_config3_line_names_the_fused_chain():
