@@ -65,6 +65,7 @@ struct BiquadArgs {
     double *seg;      // [T][nseries][S][2]: end states of pass 1, start states after pass 2
     int seglen, T;    // frames per segment (the last one may be shorter), segments per series
     int blocks_per_seg;
+    int sstride, soff;  // tile kernel, one pass: doubles between two series' states, and this cascade's first one (a cascade run as two halves)
     int spb;          // few series (< a workgroup's lanes): segments per workgroup, lanes = (segment, series); 0 = one segment
 };
 
@@ -317,7 +318,6 @@ struct BiquadLookArgs {
     unsigned long long *aggr, *incl;  // [T][nseries][2 S] doubles as two tagged words each
     unsigned *ticket, *ticket_next;   // [nl] tiles started per Line: this launch's counters, the next launch's
     const double *tab;                // [256][2 S][2 S]: A^g
-    double *state_out;                // the series' state after this call (copied over `state` after the launch)
     int *err;                         // host-visible: a look-back that gave up
     unsigned epoch;
     int nl;
@@ -565,16 +565,18 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             for (int k = tile - 1;;) {
                 double v[N];
                 bool last = false, got = false;
-                if (k < 0) {
+                if (k < 0) {  // (tile 0 only: see below)
 #pragma unroll
                     for (int i = 0; i < N; ++i)
-                        v[i] = a.state[series * N + i];
+                        v[i] = a.state[series * a.sstride + a.soff + i];
                     last = got = true;
                 } else {
+                    // tile 0 is asked for its TRUE end state only: it alone reads the series' carried state, and the
+                    // Line's last tile overwrites that state once tile 0 has published (no copy after the launch)
                     const int64_t sk = ((int64_t)k * a.nseries + series) * (2 * N);
                     if (look_read<N>(lk.incl + sk, v, lk.epoch))
                         last = got = true;
-                    else if (look_read<N>(lk.aggr + sk, v, lk.epoch))
+                    else if (k > 0 && look_read<N>(lk.aggr + sk, v, lk.epoch))
                         got = true;
                 }
                 if (got) {
@@ -676,10 +678,21 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         if constexpr (MODE == kSegSingle) {
             // the series' state after the call: with the lane that walked the Line's last frame
             if (active && tile + 1 == tiles_per_line && g == ((nreal - 1) >> kSegLog)) {
+                if (tiles_per_line > 1) {  // not before tile 0 has read the state this overwrites
+                    double v[N];
+                    unsigned spins = 0;
+                    while (!look_read<N>(lk.incl + series * (2 * N), v, lk.epoch)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 22)) {
+                            *lk.err = 2;
+                            break;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
-                    lk.state_out[series * N + 2 * k] = s1[k];
-                    lk.state_out[series * N + 2 * k + 1] = s2[k];
+                    a.state[series * a.sstride + a.soff + 2 * k] = s1[k];
+                    a.state[series * a.sstride + a.soff + 2 * k + 1] = s2[k];
                 }
             }
         }
@@ -1280,6 +1293,8 @@ public:
         a.C = cfg.channels;
         a.S = S_;
         a.nseries = nl * cfg.channels;
+        a.sstride = 2 * S_;
+        a.soff = 0;
         a.gain = gain_;
         a.in_bytes = (int64_t)dtype_size(in_dtype) * frames * cfg.channels * nl;
         a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * nl;
@@ -1423,9 +1438,6 @@ public:
 #undef PH_BT
 #undef PH_BT3
 #undef PH_BT4
-            if (single)  // the series' new state over the old one (tiles of this launch read the old one at any time)
-                PH_HIP(hipMemcpyAsync(a.state, lk.state_out, sizeof(double) * (size_t)a.nseries * 2u * (size_t)S_,
-                                      hipMemcpyDeviceToDevice, s));
         } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
@@ -1783,8 +1795,7 @@ public:
     {
         const int n = 2 * S_;
         const size_t words = (size_t)a.T * (size_t)a.nseries * 2u * (size_t)n;  // per array
-        const size_t off_state = 2 * words * sizeof(unsigned long long);
-        const size_t need = off_state + sizeof(double) * (size_t)a.nseries * n;
+        const size_t need = 2 * words * sizeof(unsigned long long);
         if (look_.bytes < need) {
             PH_TRY(look_.alloc(need + need / 2));
             PH_HIP(hipMemsetAsync(look_.p, 0, look_.bytes, s));  // (tags of a previous owner of the memory)
@@ -1840,7 +1851,6 @@ public:
             e = ++epochs;
         lk->aggr = static_cast<unsigned long long *>(look_.p);
         lk->incl = lk->aggr + words;
-        lk->state_out = reinterpret_cast<double *>(static_cast<char *>(look_.p) + off_state);
         lk->ticket = static_cast<unsigned *>(ticket_.p) + (size_t)tick_set_ * cfg.lines + win_first;
         lk->ticket_next = static_cast<unsigned *>(ticket_.p) + (size_t)(tick_set_ ^ 1) * cfg.lines + win_first;
         lk->tab = static_cast<const double *>(tab_.p);
