@@ -1295,6 +1295,11 @@ public:
         a.nseries = nl * cfg.channels;
         a.sstride = 2 * S_;
         a.soff = 0;
+        if (ext_state_) {  // (half of a longer cascade: the states live in the whole cascade's array)
+            a.state = ext_state_ + (size_t)win_first * (size_t)cfg.channels * (size_t)ext_stride_;
+            a.sstride = ext_stride_;
+            a.soff = ext_off_;
+        }
         a.gain = gain_;
         a.in_bytes = (int64_t)dtype_size(in_dtype) * frames * cfg.channels * nl;
         a.out_bytes = (int64_t)dtype_size(out_dtype) * frames * cfg.channels * nl;
@@ -1333,6 +1338,8 @@ public:
         if (relaxed && S_ > kTileMaxSections && S_ <= 2 * kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
             frames >= tile_min_frames_ && split_wanted(nl))
             return run_split(d_in, in_dtype, d_out, out_dtype, frames, a, s);
+        if (ext_state_ && !tiled)
+            return PIPE_HIP_EINVAL;  // (only the one-pass tile kernel knows the stride: run_split checked)
         PH_TRY(timer.begin(s));
         if (tiled) {
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
@@ -1371,6 +1378,8 @@ public:
             const int cmagic = (65536 + tc - 1) / tc;
             const bool single = !std::getenv("PIPE_HIP_BIQUAD_TWO_PASS");
             BiquadLookArgs lk{};
+            if (ext_state_ && !single)
+                return PIPE_HIP_EINVAL;
             if (single) {
                 PH_TRY(prepare_look(&lk, a, seg, nl, tgrid.x, s));
             } else {
@@ -1773,8 +1782,20 @@ public:
         const size_t row = sizeof(double) * (size_t)n, wa = sizeof(double) * 2u * (size_t)sa, wb = sizeof(double) * 2u * (size_t)sb;
         double *sta = static_cast<double *>(half_[0]->state_.p) + (size_t)win_first * cfg.channels * 2u * sa;
         double *stb = static_cast<double *>(half_[1]->state_.p) + (size_t)win_first * cfg.channels * 2u * sb;
-        PH_HIP(hipMemcpy2DAsync(sta, wa, a.state, row, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
-        PH_HIP(hipMemcpy2DAsync(stb, wb, a.state + 2 * sa, row, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        // the one-pass tile kernel reads and writes a series' state at any stride: the halves then work on this
+        // handle's array itself; any other form of a half (an A/B switch, a half that must stay exact) works on a copy
+        const bool direct = !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") && !std::getenv("PIPE_HIP_BIQUAD_TWO_PASS") &&
+                            !std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES") && !std::getenv("PIPE_HIP_BIQUAD_SPLIT_COPIES") &&
+                            half_[0]->relaxed_ok() && half_[1]->relaxed_ok();
+        for (int h = 0; h < 2; ++h) {
+            half_[h]->ext_state_ = direct ? static_cast<double *>(state_.p) : nullptr;
+            half_[h]->ext_stride_ = n;
+            half_[h]->ext_off_ = h ? 2 * sa : 0;
+        }
+        if (!direct) {
+            PH_HIP(hipMemcpy2DAsync(sta, wa, a.state, row, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+            PH_HIP(hipMemcpy2DAsync(stb, wb, a.state + 2 * sa, row, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        }
         for (int h = 0; h < 2; ++h)
             half_[h]->set_window(win_first, win_count);
         half_[0]->relaxed_f64_out = true;
@@ -1782,8 +1803,10 @@ public:
         half_[1]->set_post_gain(has_gain_, gain_);
         PH_TRY(half_[0]->run(d_in, in_dtype, mid_.p, PIPE_HIP_F64, frames, s));
         PH_TRY(half_[1]->run(mid_.p, PIPE_HIP_F64, d_out, out_dtype, frames, s));
-        PH_HIP(hipMemcpy2DAsync(a.state, row, sta, wa, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
-        PH_HIP(hipMemcpy2DAsync(a.state + 2 * sa, row, stb, wb, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        if (!direct) {
+            PH_HIP(hipMemcpy2DAsync(a.state, row, sta, wa, wa, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+            PH_HIP(hipMemcpy2DAsync(a.state + 2 * sa, row, stb, wb, wb, (size_t)a.nseries, hipMemcpyDeviceToDevice, s));
+        }
         PH_TRY(timer.end(s));
         const bool tiles = std::strstr(half_[0]->last_kernel, "biquad_tile_kernel") && std::strstr(half_[1]->last_kernel, "biquad_tile_kernel");
         last_kernel = tiles ? "biquad_tile_kernel<segmented, two halves of the cascade>" : "biquad_kernel<segmented, two halves of the cascade>";
@@ -1956,6 +1979,8 @@ private:
     int pw_seg_ = -1;
     double kappa_ = -1.0;
     std::unique_ptr<Biquad> half_[2];
+    double *ext_state_ = nullptr;
+    int ext_stride_ = 0, ext_off_ = 0;
     DevBuf mid_;
     // (3 sections, 16.7 M samples: 1 Line x 2 ch 113 Gsamples/s against the lane walk's 12, 64 x 2 ch 120 against 48,
     // 2048 x 2 ch even; 512 x 8 ch 127 against 218)

@@ -38,7 +38,7 @@ for it in range(iters):
     shape = str(rng.choice(["b", "b", "bg", "gb", "bgg"]))
     inplace = shape == "b" and rng.random() < 0.3
     for knob in ("PIPE_HIP_BIQUAD_NO_TILE", "PIPE_HIP_BIQUAD_NO_WAVE_SCAN", "PIPE_HIP_BIQUAD_TILE_SEG32", "PIPE_HIP_BIQUAD_TWO_PASS",
-                 "PIPE_HIP_BIQUAD_NO_SPLIT"):
+                 "PIPE_HIP_BIQUAD_NO_SPLIT", "PIPE_HIP_BIQUAD_SPLIT_COPIES"):
         os.environ.pop(knob, None)
         if rng.random() < 0.2:
             os.environ[knob] = "1"
