@@ -1761,7 +1761,8 @@ public:
         if (std::getenv("PIPE_HIP_BIQUAD_NO_SPLIT"))
             return false;
         const char *e = std::getenv("PIPE_HIP_BIQUAD_SPLIT_MAX_SERIES");
-        return (int64_t)nl * cfg.channels <= (e ? std::atoll(e) : kSplitMaxSeries);
+        // (one channel: the lane walk drags a cache line per lane whatever the number of Lines -- 4096 x 1 ch, 3 sections: 68)
+        return (int64_t)nl * cfg.channels <= (e ? std::atoll(e) : kSplitMaxSeries) || (cfg.channels == 1 && !e);
     }
     int run_split(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames, const BiquadArgs &a, hipStream_t s)
     {

@@ -56,7 +56,7 @@ print(json.dumps({'channels': $c, 'kernel': r['kernel'], 'avg_kernel_ms': r['avg
 done
 python scripts/fir_exact_sweep.py > $OUT/fir_exact_sweep.txt 2>&1
 # the segmented biquad over shapes: one-pass tile form, 1 and 2 sections; two-pass tiles and the lane walk beside it
-( for sct in 1 2; do echo "== sections $sct"; PROBE_SECTIONS=$sct python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu; done
+( for sct in 1 2 3 4; do echo "== sections $sct"; PROBE_SECTIONS=$sct python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu; done
   echo "== two passes + scan kernel (PIPE_HIP_BIQUAD_TWO_PASS)"; PIPE_HIP_BIQUAD_TWO_PASS=1 python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu
   echo "== lane walk (PIPE_HIP_BIQUAD_NO_TILE)"; PIPE_HIP_BIQUAD_NO_TILE=1 python scripts/biquad_shapes_probe.py 2>&1 | grep -v amdgpu ) > $OUT/biquad_shapes.txt
 ( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && PROBE_ONLY_C=2,8 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bqprof -o bq -- python scripts/biquad_shapes_probe.py ) < /dev/null > /dev/null 2>&1
