@@ -20,8 +20,11 @@ N > 1 runs one rank per GPU, three ways to start them (the Lines each rank gets 
     owns Line r.
   2: configs[2], 64 Lines x 256 buffers of 4096 x 2, the same FIR; the 64 Lines are dealt to the
     ranks (Line i on rank i mod N) -- strong scaling.
-  3: configs[3], 512 Lines x 8 channels x one 4096-frame buffer, FIR-256 -> biquad -> gain as one
-    fused kernel; Line i on rank i mod N -- strong scaling (SURVEY.md 8d "C4").
+  3: configs[3], 512 Lines x 8 channels x 4096-frame buffers, FIR-256 -> biquad -> gain as one
+    fused kernel; Line i on rank i mod N, and every Line advances by N buffers per step (one at N = 1):
+    a rank's launch then always holds 512 Line-buffers and fills its GPU -- per-rank work constant,
+    "weak" (SURVEY.md 8d "C4"; `--buffers 1` gives the strong-scaling launch, `scale_projection` in the
+    N = 1 line says what each costs).
 Lines share no state (run.go:112-132): no data-path collective in any of them; RCCL carries only
 the barrier and the max-over-ranks of the timed region.
 
@@ -66,6 +69,9 @@ def parse():
     ap.add_argument("--threads", action="store_true",
                     help="N > 1 as threads of ONE process (one per GPU, no process group) instead of N processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the loaded window that samples socket power / shader clock")
+    ap.add_argument("--power-window", type=float, default=2.5, help="seconds of the headline launch under the power sampler")
+    ap.add_argument("--no-scale-projection", action="store_true", help="skip the one-GPU measurement of a rank's share (N = 1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config[2]-shape line at N = 1")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 --pmc passes of this command (N = 1)")
@@ -155,6 +161,7 @@ def live_pmc(args, want):
         return {}
     out = tempfile.mkdtemp(prefix="pipe_bench_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc",
+             "--no-power", "--no-scale-projection",
              "--config", str(args.config), "--frames", str(args.frames), "--taps", str(args.taps), "--dtype", args.dtype]
     for name in ("buffers", "channels", "lines"):
         if getattr(args, name) is not None:
@@ -190,6 +197,71 @@ def live_pmc(args, want):
         f, w = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
         res[label] = int((2 * f + w) * 1024) if f and w else None
     return res
+
+
+class PowerLog:
+    """Socket power and shader clock from the amdgpu hwmon nodes (what scripts/clock_log.py reads), sampled
+    by a thread while a loaded window runs.  Every card in sysfs is sampled; the one whose median power is
+    highest under load is this process's GPU (a box may list more cards than HIP sees)."""
+
+    def __init__(self, period=0.01):
+        import threading
+        self.period, self.stop, self.nodes, self.samples = period, threading.Event(), [], []
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            n = {}
+            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                for name in ("freq1_input", "power1_average", "power1_input"):
+                    q = os.path.join(hw, name)
+                    if os.path.exists(q):
+                        n.setdefault("power" if name.startswith("power") else "sclk", q)
+            if "power" in n:
+                self.nodes.append(n)
+                self.samples.append([])
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            for n, out in zip(self.nodes, self.samples):
+                pw = self._read(n["power"])
+                ck = self._read(n["sclk"]) if "sclk" in n else None
+                if pw is not None:
+                    out.append((pw / 1e6, ck / 1e6 if ck else None))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.nodes:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.nodes:
+            self.thread.join()
+        return False
+
+    def summary(self):
+        """Medians of the card with the highest median power; None without hwmon nodes."""
+        best = None
+        for out in self.samples:
+            # (the first fifth of the window is the ramp)
+            body = out[len(out) // 5:]
+            if len(body) < 5:
+                continue
+            pw = sorted(x[0] for x in body)
+            ck = sorted(x[1] for x in body if x[1])
+            row = {"power_w": round(pw[len(pw) // 2], 1), "power_w_p90": round(pw[int(len(pw) * 0.9)], 1),
+                   "sclk_mhz": round(ck[len(ck) // 2], 0) if ck else None, "samples": len(body)}
+            if best is None or row["power_w"] > best["power_w"]:
+                best = row
+        return best
 
 
 def free_port() -> int:
@@ -295,8 +367,8 @@ def run_rank(args, rank, world, local, sync, launch):
     F, N = args.frames, args.taps
     cfg = args.config
     C = args.channels or (8 if cfg == 3 else 2)
-    K = args.buffers or {1: 131072, 2: 256, 3: 1}[cfg]
     my_lines, total_lines, scaling = shard.plan_lines(cfg, rank, world, args.lines)
+    K, scaling = shard.plan_buffers(cfg, world, args.buffers, scaling)
     L = len(my_lines)
     assert L >= 1, "more ranks than Lines"
     frames_per_line = F * K
@@ -312,11 +384,19 @@ def run_rank(args, rank, world, local, sync, launch):
         proc = fir
     proc.start()
 
-    # synthetic input, generated on the device
-    d_in = torch.empty(n_elems, dtype=t_dtype, device=dev)
-    d_out = torch.empty_like(d_in)
-    for l, gl in enumerate(my_lines):
-        P.synth_fill(d_in[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl))
+    # synthetic input, generated on the device.  Configs 2 / 3 step over a working set that would fit the
+    # 256 MiB Infinity Cache (config 3: 64 MiB in, 64 MiB out): they rotate through `nsets` distinct
+    # input / output sets, more than 640 MiB together, so that every launch streams from and to HBM.
+    itemsize = 4 if args.dtype == "f32" else 8
+    nsets = 1 if cfg == 1 else max(1, min(32, -(-(640 << 20) // (2 * n_elems * itemsize))))
+    d_ins, d_outs = [], []
+    for j in range(nsets):
+        t = torch.empty(n_elems, dtype=t_dtype, device=dev)
+        for l, gl in enumerate(my_lines):
+            P.synth_fill(t[l * frames_per_line * C:(l + 1) * frames_per_line * C], synth.line_seed(gl + 4096 * j))
+        d_ins.append(t)
+        d_outs.append(torch.empty_like(t))
+    d_in, d_out = d_ins[0], d_outs[0]
     torch.cuda.synchronize(dev)
     # The timed launches go to ONE stream named explicitly (torch's default stream has the NULL handle,
     # which the C ABI reads as "the handle's own stream" and the Python harness then brackets with
@@ -325,10 +405,14 @@ def run_rank(args, rank, world, local, sync, launch):
     stream = bench_stream.cuda_stream
 
     def timed(p, steps, warmup, d_i, d_o, fpl, barrier=False, call=None):
-        """(elapsed s, kernel ms total, launches, kernel name) of `steps` passes after `warmup`."""
-        call = call or (lambda: p.process_batch(d_i, d_o, fpl, stream=stream))
-        for _ in range(warmup):
-            call()
+        """(elapsed s, kernel ms total, launches, kernel name) of `steps` passes after `warmup`.
+        `call` may be a LIST of calls: they are taken in turn (launch i runs calls[i % len]) -- distinct
+        input / output sets rotated through the loop, so that no launch finds its buffers in the
+        256 MiB Infinity Cache from the launch before."""
+        calls = call if isinstance(call, (list, tuple)) else [call or (lambda: p.process_batch(d_i, d_o, fpl, stream=stream))]
+        nc = len(calls)
+        for i in range(warmup):
+            calls[i % nc]()
         torch.cuda.synchronize(dev)
         p.set_profiling(True)  # hipEvents attached to the dominant kernel's own dispatch
         p.kernel_time(reset=True)
@@ -336,8 +420,8 @@ def run_rank(args, rank, world, local, sync, launch):
             sync.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            call()
+        for i in range(steps):
+            calls[(warmup + i) % nc]()
         torch.cuda.synchronize(dev)
         if barrier:
             sync.barrier()
@@ -365,8 +449,25 @@ def run_rank(args, rank, world, local, sync, launch):
             for _ in range(50):
                 proc.process_batch(d_in, d_out, frames_per_line, stream=stream)
             torch.cuda.synchronize(dev)
+    main_calls = [(lambda a=a_, b=b_: proc.process_batch(a, b, frames_per_line, stream=stream)) for a_, b_ in zip(d_ins, d_outs)]
     elapsed, kernel_ms, launches, kname = timed(proc, args.steps, args.warmup, d_in, d_out, frames_per_line,
-                                                barrier=True)
+                                                barrier=True, call=main_calls)
+    power = None
+    if rank == 0 and cfg == 1 and not args.no_power:
+        # socket power and shader clock over a loaded window of the SAME launch (>= 2.5 s; hwmon, 10 ms
+        # samples, the first fifth dropped): the headline kernel runs at the package power cap, and the
+        # clock it is held at belongs next to the roofline fraction
+        with PowerLog() as plog:
+            t_pw, n_pw = time.perf_counter(), 0
+            while time.perf_counter() - t_pw < args.power_window:
+                for _ in range(20):
+                    proc.process_batch(d_in, d_out, frames_per_line, stream=stream)
+                torch.cuda.synchronize(dev)
+                n_pw += 20
+        power = plog.summary()
+        if power:
+            power["window_s"] = round(time.perf_counter() - t_pw, 2)
+            power["launches"] = n_pw
     elapsed = sync.max(elapsed)
     total_samples_per_step = int(sync.sum(n_elems)) if world > 1 else n_elems
 
@@ -402,8 +503,8 @@ def run_rank(args, rank, world, local, sync, launch):
            f"{K} consecutive buffers resident in HBM per step",
         2: f"configs[2]: {total_lines} Lines x {C} ch x {K} buffers of {F} frames x {N}-tap FIR, "
            f"Line i on GPU i mod {world}, one launch per step",
-        3: f"configs[3]: {total_lines} Lines x {C} ch x {F}-frame buffer, {N}-tap FIR -> biquad -> gain "
-           f"(one fused kernel), Line i on GPU i mod {world}",
+        3: f"configs[3]: {total_lines} Lines x {C} ch x {F}-frame buffers, {N}-tap FIR -> biquad -> gain "
+           f"(one fused kernel), Line i on GPU i mod {world}, every Line advances by {K} buffer(s) per step",
     }[cfg]
     result = {
         "metric": "Msamples/sec through 256-tap FIR Processor, 48 kHz 2 ch, 1/2/4/8 GPU + CPU ref",  # BASELINE.json's metric, verbatim
@@ -460,23 +561,56 @@ def run_rank(args, rank, world, local, sync, launch):
             "f64_peak_tflops": F64_VALU_PEAK_TFLOPS,
         }
 
-    # SURVEY.md 8(d) "C3" shape next to the headline (N = 1, config 1 only): 64 Lines x 256 buffers,
-    # after a warm-up long enough to be at steady state (short launches after an idle period read
-    # the clock ramp, docs/NOTEBOOK.md section 4)
+    if power:
+        result["roofline"]["power"] = power  # medians over the loaded window: the clock the fraction was reached at
+
+    # ---- the other BASELINE configs next to the headline (N = 1, config 1 only) ----------------------------
+    # Every "fraction of HBM" below is a STREAMING figure: the timed launches rotate through distinct
+    # input / output sets that together exceed twice the 256 MiB Infinity Cache (inputs: slices of the
+    # headline's 4 GiB input at different offsets; outputs: slices of one 1.25 GiB arena), so no launch
+    # finds its buffers in the cache from the launch before.  The same launch over ONE set (what earlier
+    # rounds reported) rides beside it as `roofline_frac_l3_resident`.
     if cfg == 1 and world == 1 and not args.no_secondary and args.dtype == "f32":
-        del d_out
+        del d_out, d_outs, main_calls
+        ARENA = 320 << 20  # elements: 1.25 GiB of float32
+        arena = torch.empty(ARENA, dtype=t_dtype, device=dev)
+        if d_in.numel() < ARENA:  # (a --buffers smaller than the default: its own synthetic input)
+            d_src = torch.empty(ARENA, dtype=t_dtype, device=dev)
+            P.synth_fill(d_src, synth.line_seed(7))
+            torch.cuda.synchronize(dev)
+        else:
+            d_src = d_in
+
+        def sets_of(n_in, n_out, min_bytes=640 << 20, max_sets=48):
+            """[(input slice, output slice)]: distinct sets, >= min_bytes together (256-byte aligned starts)."""
+            ai, ao = -(-n_in // 64) * 64, -(-n_out // 64) * 64
+            k = max(2, min(max_sets, -(-min_bytes // ((n_in + n_out) * itemsize))))
+            k = min(k, d_src.numel() // ai, ARENA // ao)
+            return [(d_src[q * ai:q * ai + n_in], arena[q * ao:q * ao + n_out]) for q in range(k)]
+
+        def both(p, n_in, n_out, fpl, steps, warmup, alg_bytes, mk_call=None):
+            """The launch timed over ONE set (cache-resident where it fits) and rotating through the sets."""
+            ss = sets_of(n_in, n_out)
+            mk = mk_call or (lambda a, b: (lambda: p.process_batch(a, b, fpl, stream=stream)))
+            calls = [mk(a, b) for a, b in ss]
+            el1, k1, n1, _ = timed(p, steps, warmup, None, None, 0, call=calls[:1])
+            el, k, n, name = timed(p, steps, warmup, None, None, 0, call=calls)
+            ms1, ms = k1 / max(n1, 1), k / max(n, 1)
+            return {"kernel": name, "avg_kernel_ms": round(ms, 5), "ms_per_step": round(el / steps * 1e3, 5),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "roofline_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "roofline_frac_l3_resident": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "avg_kernel_ms_l3_resident": round(ms1, 5),
+                    "sets": len(ss), "set_bytes": (n_in + n_out) * itemsize,
+                    "warmup_launches": warmup, "timed_launches": steps}, ms
+
+        # SURVEY.md 8(d) "C3" shape: 64 Lines x 256 buffers (1 GiB per set: streaming by its size)
         L2, K2 = 64, 256
         n2 = L2 * F * K2 * C
         with P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=L2, max_batch=K2) as f2:
             f2.start()
-            if d_in.numel() >= n2:
-                di = d_in[:n2]
-            else:  # (a --buffers smaller than this shape: its own synthetic input)
-                di = torch.empty(n2, dtype=t_dtype, device=dev)
-                for l in range(L2):
-                    P.synth_fill(di[l * F * K2 * C:(l + 1) * F * K2 * C], synth.line_seed(l))
-                torch.cuda.synchronize(dev)
-            do = torch.empty_like(di)
+            di = d_src[:n2]
+            do = arena[:n2]
             _, kms2, nl2, kn2 = timed(f2, 100, 300, di, do, F * K2)
             ms2 = kms2 / max(nl2, 1)
             result["c3_shape"] = {
@@ -486,15 +620,6 @@ def run_rank(args, rank, world, local, sync, launch):
                 "roofline_frac": round(n2 * bps / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "warmup_launches": 300, "timed_launches": 100,
             }
-            del do
-
-        def own_input(n, seed_line):
-            if d_in.numel() >= n:
-                return d_in[:n]
-            t = torch.empty(n, dtype=t_dtype, device=dev)
-            P.synth_fill(t, synth.line_seed(seed_line))
-            torch.cuda.synchronize(dev)
-            return t
 
         # BASELINE configs[3] (SURVEY 8d "C4") at N = 1: 512 Lines x 8 ch x one 4096-frame buffer through
         # FIR-256 -> biquad -> gain as ONE fused kernel; the same launch `--config 3` times
@@ -504,20 +629,11 @@ def run_rank(args, rank, world, local, sync, launch):
         with P.Chain([P.Fir(taps, F, C4, **kw4), P.Biquad(synth.biquad_rbj_lowpass(), F, C4, **kw4),
                       P.Gain(0.7071067811865476, F, C4, **kw4)]) as ch4:
             ch4.start()
-            di = own_input(n4, 0)
-            do = torch.empty_like(di)
-            el4, kms4, nl4, kn4 = timed(ch4, 400, 600, di, do, F)
-            ms4 = kms4 / max(nl4, 1)
-            result["c4_chain"] = {
-                "workload": f"configs[3]: {L4} Lines x {C4} ch x {F}-frame buffer, {N}-tap FIR -> biquad -> gain, one launch per step",
-                "kernel": kn4, "avg_kernel_ms": round(ms4, 5), "ms_per_step": round(el4 / 400 * 1e3, 5),
-                "msamples_per_s": round(n4 / (el4 / 400) / 1e6, 1),
-                "algorithmic_bytes_per_launch": n4 * bps,
-                "roofline_frac": round(n4 * bps / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": committed_traffic(kn4, n4 * bps),
-                "warmup_launches": 600, "timed_launches": 400,
-            }
-            del do
+            r4, ms4 = both(ch4, n4, n4, F, 400, 600, n4 * bps)
+            r4["workload"] = f"configs[3]: {L4} Lines x {C4} ch x {F}-frame buffer, {N}-tap FIR -> biquad -> gain, one launch per step"
+            r4["msamples_per_s"] = round(n4 / (r4["ms_per_step"] * 1e-3) / 1e6, 1)
+            r4["traffic"] = committed_traffic(r4["kernel"], n4 * bps)
+            result["c4_chain"] = r4
 
         # the biquad stage alone (no BASELINE config of its own; configs[3] runs it fused): the time-segmented
         # form through LDS tiles, one pass, on the configs[3] shape and on ONE stereo Line of the same sample count
@@ -526,15 +642,11 @@ def run_rank(args, rank, world, local, sync, launch):
             nb = Lb * Kb * F * Cb
             with P.Biquad(synth.biquad_rbj_lowpass(), F, Cb, dtype=np_dtype, device=local, lines=Lb, max_batch=Kb) as bqp:
                 bqp.start()
-                di = own_input(nb, 0)
-                do = torch.empty_like(di)
-                _, kmsb, nlb, knb = timed(bqp, 200, 300, di, do, Kb * F)
-                msb = kmsb / max(nlb, 1)
-                bq[tag] = {"workload": f"{Lb} Lines x {Cb} ch x {Kb} buffers of {F} frames, 1 section", "kernel": knb,
-                           "avg_ms": round(msb, 5), "msamples_per_s": round(nb / (msb * 1e-3) / 1e6, 1),
-                           "algorithmic_bytes_per_launch": nb * bps,
-                           "roofline_frac": round(nb * bps / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-                del do
+                rb, _ = both(bqp, nb, nb, Kb * F, 200, 300, nb * bps)
+                rb["workload"] = f"{Lb} Lines x {Cb} ch x {Kb} buffers of {F} frames, 1 section"
+                rb["avg_ms"] = rb["avg_kernel_ms"]
+                rb["msamples_per_s"] = round(nb / (rb["avg_kernel_ms"] * 1e-3) / 1e6, 1)
+                bq[tag] = rb
         result["biquad_alone"] = bq
 
         # BASELINE configs[4]: the 44.1 -> 48 kHz polyphase resampler (160/147, 24 taps per phase) over
@@ -543,43 +655,121 @@ def run_rank(args, rank, world, local, sync, launch):
         T5, up5, down5, K5 = 24, 160, 147, 1024
         n_in5 = K5 * F
         cap5 = -(-n_in5 * up5 // down5) + 1
+        got = [0]
         with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C, dtype=np_dtype, device=local,
                          max_batch=K5) as rs:
             rs.start()
-            di = own_input(n_in5 * C, 0)
-            do = torch.empty(cap5 * C, dtype=t_dtype, device=dev)
-            got = [0]
 
-            def rs_call():
-                got[0] = rs.resample_batch(di, n_in5, do, cap5, stream=stream)
-            _, kms5, nl5, kn5 = timed(rs, 200, 300, None, None, 0, call=rs_call)
-            ms5 = kms5 / max(nl5, 1)
+            def rs_mk(a, b):
+                def call():
+                    got[0] = rs.resample_batch(a, n_in5, b, cap5, stream=stream)
+                return call
+            rs_mk(d_src[:n_in5 * C], arena[:cap5 * C])()  # (the output frame count of such a call)
+            torch.cuda.synchronize(dev)
             by5 = (n_in5 + got[0]) * C * 4
+            r5, ms5 = both(rs, n_in5 * C, cap5 * C, 0, 200, 300, by5, mk_call=rs_mk)
+            r5.update({"in_frames": n_in5, "out_frames": got[0],
+                       "msamples_out_per_s": round(got[0] * C / (ms5 * 1e-3) / 1e6, 1),
+                       "traffic": committed_traffic(r5["kernel"], by5)})
             c5 = {
                 "workload": f"configs[4]: 1 Line x {C} ch, {up5}/{down5} polyphase resampler ({T5} taps per phase), "
                             f"{K5} buffers of {F} frames per launch; 2-input mix of the same stream",
-                "resampler": {"kernel": kn5, "avg_kernel_ms": round(ms5, 5), "in_frames": n_in5, "out_frames": got[0],
-                              "msamples_out_per_s": round(got[0] * C / (ms5 * 1e-3) / 1e6, 1),
-                              "algorithmic_bytes_per_launch": by5,
-                              "roofline_frac": round(by5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                              "traffic": committed_traffic(kn5, by5)},
+                "resampler": r5,
             }
-            nm = got[0] * C
-            with P.Mix(2, F, C, dtype=np_dtype, device=local, max_batch=cap5 // F + 1) as mx:
-                mx.start()
-                off = (nm + 63) // 64 * 64  # (a 256-byte aligned second input: an odd element offset would put the mix on its 4-byte path)
-                other = d_in[off:off + nm] if d_in.numel() >= off + nm else own_input(nm, 1)
-                mo = torch.empty(nm, dtype=t_dtype, device=dev)
-                a5 = do[:nm]
+        # 64 such Lines in one launch (one Line x 32 us does not fill the chip)
+        L5 = 64
+        with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C, dtype=np_dtype, device=local,
+                         lines=L5, max_batch=K5 // 16) as rsl:
+            rsl.start()
+            n_in5l = (K5 // 16) * F
+            cap5l = -(-n_in5l * up5 // down5) + 1
+            gotl = [0]
 
-                def mx_call():
-                    mx.mix_batch([a5, other], mo, got[0], stream=stream)
-                _, kmsm, nlm, knm = timed(mx, 200, 300, None, None, 0, call=mx_call)
-                msm = kmsm / max(nlm, 1)
-                c5["mix"] = {"kernel": knm, "avg_kernel_ms": round(msm, 5), "algorithmic_bytes_per_launch": 3 * nm * 4,
-                             "roofline_frac": round(3 * nm * 4 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-            result["c5_resampler_mix"] = c5
-            del do
+            def rsl_mk(a, b):
+                def call():
+                    gotl[0] = rsl.resample_batch(a, n_in5l, b, cap5l, stream=stream)
+                return call
+            rsl_mk(d_src[:L5 * n_in5l * C], arena[:L5 * cap5l * C])()
+            torch.cuda.synchronize(dev)
+            by5l = L5 * (n_in5l + gotl[0]) * C * 4
+            r5l, ms5l = both(rsl, L5 * n_in5l * C, L5 * cap5l * C, 0, 200, 300, by5l, mk_call=rsl_mk)
+            r5l.update({"lines": L5, "in_frames_per_line": n_in5l, "out_frames_per_line": gotl[0],
+                        "msamples_out_per_s": round(L5 * gotl[0] * C / (ms5l * 1e-3) / 1e6, 1)})
+            c5["resampler_64_lines"] = r5l
+        nm = got[0] * C
+        with P.Mix(2, F, C, dtype=np_dtype, device=local, max_batch=cap5 // F + 1) as mx:
+            mx.start()
+            am = -(-nm // 64) * 64  # (256-byte aligned inputs: an odd element offset would put the mix on its 4-byte path)
+            km = max(2, min(16, -(-(640 << 20) // (3 * nm * 4))))
+            mcalls = []
+            for q in range(km):
+                a5, b5, mo = d_src[(2 * q) * am:(2 * q) * am + nm], d_src[(2 * q + 1) * am:(2 * q + 1) * am + nm], arena[q * am:q * am + nm]
+                mcalls.append(lambda a5=a5, b5=b5, mo=mo: mx.mix_batch([a5, b5], mo, got[0], stream=stream))
+            _, k1, n1, _ = timed(mx, 200, 300, None, None, 0, call=mcalls[:1])
+            _, kmsm, nlm, knm = timed(mx, 200, 300, None, None, 0, call=mcalls)
+            msm, msm1 = kmsm / max(nlm, 1), k1 / max(n1, 1)
+            c5["mix"] = {"kernel": knm, "avg_kernel_ms": round(msm, 5), "algorithmic_bytes_per_launch": 3 * nm * 4,
+                         "roofline_frac": round(3 * nm * 4 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "roofline_frac_l3_resident": round(3 * nm * 4 / (msm1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "sets": km, "set_bytes": 3 * nm * 4}
+        result["c5_resampler_mix"] = c5
+
+        # the HBM reference point: the gain Processor (1 flop per sample) streaming 1 GiB in, 1 GiB out
+        ng = 256 << 20
+        with P.Gain(0.5, F, C, dtype=np_dtype, device=local, max_batch=ng // (F * C)) as gp:
+            gp.start()
+            gcalls = [lambda: gp.process_batch(d_src[:ng], arena[:ng], ng // C, stream=stream)]
+            _, kg, ngl, kng = timed(gp, 50, 20, None, None, 0, call=gcalls)
+            msg = kg / max(ngl, 1)
+            result["gain_reference"] = {
+                "workload": "gain Processor, 1 GiB in + 1 GiB out per launch (streaming by its size)",
+                "kernel": kng, "avg_kernel_ms": round(msg, 5), "algorithmic_bytes_per_launch": 2 * ng * 4,
+                "roofline_frac": round(2 * ng * 4 / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+        # ---- what a rank's share costs (one GPU; no multi-GPU hardware is needed for this) ---------------------
+        # configs[3] / configs[2] deal their Lines to G ranks: rank r runs total / G Lines.  t(L) below is one
+        # launch over L Lines on THIS GPU (streaming sets); the projected speed-up of G GPUs is
+        # t(total) / t(total / G) -- Lines share nothing, the only cross-rank cost is the barrier.  With few Lines
+        # a launch no longer fills the chip (configs[3] at G = 8: 768 units for 2048 waves), so `--config 3 --gpus G`
+        # advances every Line by K = G buffers per launch (per-rank work constant, shard.plan_buffers): the
+        # `k_plan` rows are that launch -- t(total / G Lines x G buffers), efficiency against t(total Lines x 1).
+        if not args.no_scale_projection:
+            sp = {"method": "one GPU; t(L) = avg kernel ms of one launch over L Lines (streaming sets), "
+                            "speedup(G) = t(total) / t(total / G), efficiency = speedup / G"}
+            rows3, t3 = [], {}
+            for Lr, Kr in ((512, 1), (256, 1), (128, 1), (64, 1), (256, 2), (128, 4), (64, 8)):
+                kwr = dict(dtype=np_dtype, device=local, lines=Lr, max_batch=Kr)
+                nr = Lr * Kr * F * C4
+                with P.Chain([P.Fir(taps, F, C4, **kwr), P.Biquad(synth.biquad_rbj_lowpass(), F, C4, **kwr),
+                              P.Gain(0.7071067811865476, F, C4, **kwr)]) as chr_:
+                    chr_.start()
+                    rr, msr = both(chr_, nr, nr, Kr * F, 200, 300, nr * bps)
+                    t3[(Lr, Kr)] = msr
+                    rows3.append({"lines": Lr, "buffers_per_line": Kr, "kernel": rr["kernel"], "ms": round(msr, 5),
+                                  "roofline_frac": rr["roofline_frac"]})
+            sp["config3"] = {
+                "rows": rows3,
+                "strong": {str(G): {"speedup": round(t3[(512, 1)] / t3[(512 // G, 1)], 3),
+                                    "efficiency": round(t3[(512, 1)] / t3[(512 // G, 1)] / G, 3)} for G in (2, 4, 8)},
+                # K = G buffers per Line per launch: a rank's launch does the work of the N = 1 launch
+                "k_plan": {str(G): {"efficiency": round(t3[(512, 1)] / t3[(512 // G, G)], 3)} for G in (2, 4, 8)},
+            }
+            rows2, t2 = [], {}
+            for Lr in (64, 32, 16, 8):
+                nr = Lr * K2 * F * C
+                with P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=Lr, max_batch=K2) as fr:
+                    fr.start()
+                    _, kr, nlr, knr = timed(fr, 60, 100, d_src[:nr], arena[:nr], F * K2)
+                    t2[Lr] = kr / max(nlr, 1)
+                    rows2.append({"lines": Lr, "buffers_per_line": K2, "kernel": knr, "ms": round(t2[Lr], 5),
+                                  "roofline_frac": round(nr * bps / (t2[Lr] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+            sp["config2"] = {
+                "rows": rows2,
+                "strong": {str(G): {"speedup": round(t2[64] / t2[64 // G], 3),
+                                    "efficiency": round(t2[64] / t2[64 // G] / G, 3)} for G in (2, 4, 8)},
+            }
+            result["scale_projection"] = sp
+        del arena
 
     # roofline.traffic measured in THIS run (N = 1): the committed figure above stays only if the passes fail
     if rank == 0 and world == 1 and not args.no_live_pmc and os.environ.get("PIPE_BENCH_LIVE_PMC", "1") != "0":

@@ -30,6 +30,22 @@ def plan_lines(config: int, rank: int, world: int, lines: Optional[int] = None):
     return line_indices(rank, world, total), total, "strong"
 
 
+def plan_buffers(config: int, world: int, buffers: Optional[int] = None, scaling: str = "strong"):
+    """Consecutive pipe buffers every Line advances by per step, and the scaling label that goes with it.
+      config 1: 131072 (the whole stream of the step resident); config 2: 256;
+      config 3: `world` -- with 512 / world Lines a one-buffer launch no longer fills a GPU (at 8 ranks:
+      768 units for 2048 waves), so every rank's launch takes `world` buffers of each of its Lines: the
+      launch holds 512 Line-buffers whatever the rank count, per-rank work is constant ("weak").
+    An explicit `buffers` keeps the label plan_lines gave (config 3 --buffers 1: strong scaling)."""
+    if buffers:
+        return int(buffers), scaling
+    if config == 1:
+        return 131072, scaling
+    if config == 2:
+        return 256, scaling
+    return max(1, world), ("weak" if world > 1 else scaling)
+
+
 def rank_from_env() -> Tuple[int, int, int]:
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
             int(os.environ.get("LOCAL_RANK", "0")))
@@ -42,7 +58,11 @@ def init(backend: str, rank: int, world: int, device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    kw = {}
+    import datetime
+    # a rank whose first collective never completes (a peer died in RCCL's setup) must not hang the others
+    # for ever: ProcessSync.settle() then falls through to the gloo agreement
+    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("PIPE_BENCH_DIST_TIMEOUT_S", "180")))}
+    del device  # (RCCL's communicator is made by the first device collective, inside settle()'s try: no device_id)
     if backend == "nccl":
         # RCCL for device tensors, gloo for host tensors: ProcessSync.settle() falls back to the
         # latter if the first RCCL collective fails (the data path has no collective to lose)

@@ -61,6 +61,23 @@ def test_default_line_has_every_contract_field():
         assert 0 < b["roofline_frac"] < 1.0
     tb = d["biquad_alone"].get("traffic")   # (live PMC passes; absent without rocprofv3)
     assert tb is None or 1.0 <= tb / (8 * 512 * 4096 * 8) < 1.2
+    # every "of HBM" figure is a streaming one: the timed launches rotate through sets that exceed twice the
+    # 256 MiB Infinity Cache; the one-set (cache-resident) figure rides beside it
+    for o in (c4, r5, c5["resampler_64_lines"], c5["mix"], d["biquad_alone"]["lines_512x8"], d["biquad_alone"]["one_stereo_line"]):
+        assert o["sets"] >= 2 and o["sets"] * o["set_bytes"] >= 512 << 20
+        assert 0 < o["roofline_frac"] < 0.85 and 0 < o["roofline_frac_l3_resident"] < 1.0
+    g = d["gain_reference"]
+    assert g["kernel"].startswith("gain_kernel") and 0.5 < g["roofline_frac"] < 0.85   # (the guide's achievable HBM rate: ~0.79)
+    # socket power and shader clock over a loaded window of the headline launch (hwmon; None where the box has no such node)
+    pw = r.get("power")
+    assert pw is None or (pw["window_s"] >= 2.0 and 200 < pw["power_w"] < 1600 and (pw["sclk_mhz"] is None or 500 < pw["sclk_mhz"] < 2600))
+    # a rank's share on one GPU: t(L) of configs[3] / configs[2] and the projected efficiency at 2 / 4 / 8 GPUs
+    sp = d["scale_projection"]
+    assert [(x["lines"], x["buffers_per_line"]) for x in sp["config3"]["rows"]] == [(512, 1), (256, 1), (128, 1), (64, 1), (256, 2), (128, 4), (64, 8)]
+    assert set(sp["config3"]["strong"]) == set(sp["config3"]["k_plan"]) == set(sp["config2"]["strong"]) == {"2", "4", "8"}
+    t3 = {(x["lines"], x["buffers_per_line"]): x["ms"] for x in sp["config3"]["rows"]}
+    assert abs(sp["config3"]["k_plan"]["8"]["efficiency"] - t3[(512, 1)] / t3[(64, 8)]) < 0.02
+    assert sp["config3"]["k_plan"]["8"]["efficiency"] > 0.7   # the plan bench.py --config 3 --gpus 8 runs fills every rank
 
 
 def test_config3_line_names_the_fused_chain():
@@ -78,10 +95,18 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     d = run_bench("--gpus", "2", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
                   "--no-live-pmc", env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
-    assert "self-spawned" in d["config"]["ranks"] and d["scaling"] == "strong"
-    # value counts BOTH ranks' samples: 512 Lines x 4096 x 8 per step over the slowest rank's time
+    # the K-per-rank plan (shard.plan_buffers): with 2 ranks every Line advances by 2 buffers per step, a rank's
+    # launch holds 512 Line-buffers like the N = 1 launch -- per-rank work constant
+    assert "self-spawned" in d["config"]["ranks"] and d["scaling"] == "weak" and d["config"]["buffers_per_step"] == 2
+    # value counts BOTH ranks' samples: 512 Lines x 2 x 4096 x 8 per step over the slowest rank's time
+    assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 2 * 4096 * 8) - 1.0) < 0.02
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 2 * 4096 * 8   # one rank's launch
+    # --buffers 1: the strong-scaling launch (256 Lines x one buffer per rank)
+    d = run_bench("--gpus", "2", "--config", "3", "--buffers", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                  "--no-live-pmc", env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
+    assert d["scaling"] == "strong" and d["config"]["buffers_per_step"] == 1
     assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 4096 * 8) - 1.0) < 0.02
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 4096 * 8   # one rank's launch
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 4096 * 8
 
 
 def test_threads_mode_is_one_process_with_a_thread_per_rank():
@@ -89,8 +114,8 @@ def test_threads_mode_is_one_process_with_a_thread_per_rank():
     d = run_bench("--gpus", "2", "--threads", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
                   env={"PIPE_BENCH_SHARE_DEVICES": "1"})
     assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
-    assert "threads" in d["config"]["ranks"]
-    assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 4096 * 8) - 1.0) < 0.02
+    assert "threads" in d["config"]["ranks"] and d["scaling"] == "weak"
+    assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 2 * 4096 * 8) - 1.0) < 0.02
     w = run_bench("--gpus", "2", "--threads", "--steps", "3", "--warmup", "1", "--buffers", "2048", "--no-cpu-baseline",
                   env={"PIPE_BENCH_SHARE_DEVICES": "1"})
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["lines_total"] == 2

@@ -47,6 +47,16 @@ def _worker(rank, world, port, total_lines, out_dir):
         assert shard.sum_over_ranks(float(len(got)), dist) == total
     got, tot, kind = shard.plan_lines(1, rank, world, 3)
     assert kind == "weak" and tot == 3 * world and len(got) == 3
+    # the K-per-rank plan of config 3: every Line advances by `world` buffers per step, so a rank's launch
+    # always holds 512 Line-buffers (per-rank work constant: "weak"); all ranks together advance the 512
+    # Lines by the same K, and an explicit --buffers keeps the strong-scaling label
+    got, tot, kind = shard.plan_lines(3, rank, world)
+    K, kind = shard.plan_buffers(3, world, None, kind)
+    assert K == world and kind == "weak" and len(got) * K == 512
+    assert shard.sum_over_ranks(float(len(got) * K), dist) == 512 * world
+    assert shard.plan_buffers(3, world, 1, "strong") == (1, "strong")
+    assert shard.plan_buffers(2, world, None, "strong") == (256, "strong")
+    assert shard.plan_buffers(1, world, None, "weak") == (131072, "weak")
     np.save(os.path.join(out_dir, f"r{rank}.npy"),
             np.array([elapsed, worst, n_lines] + [v for _, v in sorted(sums.items())] ))
     dist.destroy_process_group()
@@ -73,6 +83,20 @@ def test_two_rank_sharding_and_timing(tmp_path):
     got.update(zip(shard.line_indices(1, 2, 5), r1[3:]))
     assert got == want
     assert shard.aggregate_throughput(1000, 10, 2, 0.5) == 1000 * 2 * 10 / 0.5 / 1e6
+
+
+def test_k_per_rank_plan_fills_every_rank():
+    """config 3 dealt to G ranks: Lines x buffers per rank is the N = 1 launch's 512 for every G that divides it."""
+    sys.path.insert(0, ROOT)
+    from pipe_amd import shard
+    for world in (1, 2, 4, 8):
+        per_rank = []
+        for r in range(world):
+            mine, total, kind = shard.plan_lines(3, r, world)
+            K, kind = shard.plan_buffers(3, world, None, kind)
+            per_rank.append(len(mine) * K)
+            assert kind == ("weak" if world > 1 else "strong")
+        assert per_rank == [512] * world
 
 
 def test_thread_ranks_barrier_and_reductions():
