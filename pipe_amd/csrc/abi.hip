@@ -130,6 +130,80 @@ int validate_config(const pipe_hip_config *c)
 
 using namespace pipehip;
 
+namespace {
+// ---- uploads through the large BAR ---------------------------------------------------------------------
+// What a device offers for CPU stores straight into its memory: the large-BAR attribute and the address
+// of its HDP flush register, asked once PER DEVICE (handles of one process may sit on several GPUs).
+struct BarInfo {
+    bool known = false, large_bar = false;
+    volatile unsigned *hdp_flush = nullptr;
+};
+BarInfo bar_info(int dev)
+{
+    static std::mutex mu;
+    static BarInfo info[64];
+    std::lock_guard<std::mutex> lk(mu);
+    BarInfo &b = info[dev & 63];
+    if (!b.known) {
+        b.known = true;
+        int v = 0;
+        hipDeviceProp_t prop;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && v != 0 &&
+            hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            b.large_bar = true;
+            b.hdp_flush = prop.hdpMemFlushCntl;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return b;
+}
+// Is [p, p + bytes) mapped readable AND writable in this process?  The large-BAR attribute is a device
+// property; an allocation the runtime did not map for the host (or sits in ROCr's reserved PROT_NONE range,
+// where mincore() succeeds and a store faults) must not be written to.  /proc/self/maps says what a store
+// will find without trying one.
+bool host_writable(const void *p, size_t bytes)
+{
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+    std::FILE *f = std::fopen("/proc/self/maps", "r");
+    if (!f)
+        return false;
+    char line[512];
+    uintptr_t covered = lo;  // the range is covered up to here by writable mappings (maps are sorted)
+    while (covered < hi && std::fgets(line, sizeof line, f)) {
+        unsigned long long a = 0, b = 0;
+        char perms[8] = {0};
+        if (std::sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3)
+            continue;
+        if ((uintptr_t)b <= covered)
+            continue;
+        if ((uintptr_t)a > covered)
+            break;  // a hole
+        if (perms[0] != 'r' || perms[1] != 'w')
+            break;
+        covered = (uintptr_t)b;
+    }
+    std::fclose(f);
+    return covered >= hi;
+}
+// The rows of a chunk have been stored: make them visible to the device before the launch's doorbell.
+// The store fence orders the write-combined stores on the CPU side only; behind the BAR they pass through
+// the device's HDP write path, which is flushed by a write to its flush register (read back: the write has
+// landed) -- what the ROCm runtime does after its own copies into device memory.
+inline void bar_publish(volatile unsigned *hdp_flush)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+    if (hdp_flush) {
+        *hdp_flush = 1u;
+        (void)*hdp_flush;
+    }
+}
+}  // namespace
+
 // ---- large host calls: H2D(k + 1) | kernel(k) | D2H(k - 1) -------------------------------------
 // A call that brings many Lines (cfg.lines = L, one pipe buffer each: tens of MB) used to run
 // memcpy -> H2D -> kernels -> D2H -> memcpy strictly one after the other, the kernels 1 % of it.
@@ -153,6 +227,7 @@ struct pipe_hip_processor::Overlap {
         const std::function<const void *(int)> *in_of;
         const std::function<void *(int)> *out_of;
         bool bar = false;    // the CPU stores the rows straight into device memory (large BAR): no upload DMA
+        volatile unsigned *hdp_flush = nullptr;  // the device's HDP flush register (bar_publish)
         std::mutex enq_mu;   // the handle is not thread-safe: one chunk is queued at a time
         int rc = PIPE_HIP_OK;
         size_t finished = 0;  // chunks copied out (or given up on)
@@ -174,6 +249,9 @@ struct pipe_hip_processor::Overlap {
     Call *call = nullptr;
     bool stop = false;
     int device = 0;
+    const void *bar_checked = nullptr;  // the staging allocation host_writable() was last asked about
+    size_t bar_checked_bytes = 0;
+    bool bar_ok = false;
 
     static int copy_threads()
     {
@@ -198,7 +276,7 @@ struct pipe_hip_processor::Overlap {
                 std::memset(dst_rows + c.row_in * (size_t)i, 0, c.row_in);
         }
         if (c.bar)
-            __builtin_ia32_sfence();  // the write-combined stores have left the core before the launch's doorbell
+            bar_publish(c.hdp_flush);
         if (c.trace)
             c.tr[k * 5] = c.us();
         pipe_hip_processor *p = c.p;
@@ -322,10 +400,139 @@ struct pipe_hip_processor::Overlap {
 };
 
 // ---- shared handle plumbing ---------------------------------------------------
+// ---- PIPE_HIP_PARAM_RESIDENT: the next buffer's work queued on the device ahead of its call ------------------
+namespace {
+// Handles that have a doorbell: the watchdog looks at them, and at process exit their doorbells are rung (a
+// store each), so that no queue is left waiting for a host that has gone (a handle that was never destroyed).
+// Lock order: g_resident_mu, then a handle's resident.mu (the fast path takes only the latter).
+std::mutex g_resident_mu;
+std::vector<pipe_hip_processor *> g_resident;
+
+// spin on the completion word (the store behind the stage's kernels on the handle's stream)
+int resident_wait(pipe_hip_processor *p, unsigned k)
+{
+    const unsigned *done = p->resident.done();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != k; ++spins) {
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            // the device never answered: report it, and see what the runtime says about the stream
+            if (hipStreamQuery(p->stream) != hipErrorNotReady)
+                (void)hipGetLastError();
+            return PIPE_HIP_EHIP;
+        }
+    }
+    return PIPE_HIP_OK;
+}
+// queue the work of a buffer of `frames` frames behind the next doorbell value (resident.mu held)
+int resident_arm(pipe_hip_processor *p, int32_t frames)
+{
+    pipe_hip_processor::Resident &R = p->resident;
+    pipe_hip_processor::Staging &g = p->stg[0];
+    const unsigned k = R.seq + 1;
+    PH_HIP(hipStreamWaitValue32(p->stream, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    int64_t out_frames = frames;
+    const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, p->stream);
+    // (whatever run_var did, the stream must not be left waiting for a doorbell nobody will ring for work that
+    // is not there: the completion store is queued in every case)
+    PH_HIP(hipStreamWriteValue32(p->stream, R.done(), k, 0));
+    R.seq = k;
+    R.frames = frames;
+    R.out_frames = out_frames;
+    R.armed_at = std::chrono::steady_clock::now();
+    R.pending.store(true, std::memory_order_release);
+    return rc;
+}
+// run what is queued on whatever the staging buffer holds, and take it back (resident.mu held)
+int resident_cancel_locked(pipe_hip_processor *p)
+{
+    pipe_hip_processor::Resident &R = p->resident;
+    if (!R.pending.load(std::memory_order_acquire))
+        return PIPE_HIP_OK;
+    __atomic_store_n(R.bell(), R.seq, __ATOMIC_RELEASE);
+    R.pending.store(false, std::memory_order_release);
+    PH_TRY(resident_wait(p, R.seq));
+    p->rollback_launch();
+    return PIPE_HIP_OK;
+}
+int resident_cancel(pipe_hip_processor *p)
+{
+    if (!p->resident.mail.p)
+        return PIPE_HIP_OK;
+    std::lock_guard<std::mutex> lk(p->resident.mu);
+    return resident_cancel_locked(p);
+}
+// before a device-wide synchronisation of our own: nothing of ours may be waiting for a doorbell on that device
+void resident_cancel_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    for (pipe_hip_processor *p : g_resident)
+        if (p->cfg.device == device)
+            (void)resident_cancel(p);
+}
+void resident_ring_all()
+{
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    for (pipe_hip_processor *p : g_resident)
+        if (p->resident.pending.load() && p->resident.mail.p)
+            __atomic_store_n(p->resident.bell(), p->resident.seq, __ATOMIC_RELEASE);
+}
+void resident_watchdog()
+{
+    for (;;) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        std::lock_guard<std::mutex> lk(g_resident_mu);
+        const auto now = std::chrono::steady_clock::now();
+        for (pipe_hip_processor *p : g_resident) {
+            pipe_hip_processor::Resident &R = p->resident;
+            if (!R.pending.load(std::memory_order_acquire))
+                continue;
+            std::unique_lock<std::mutex> hl(R.mu, std::try_to_lock);
+            if (!hl.owns_lock() || !R.pending.load() || now - R.armed_at < std::chrono::milliseconds(R.idle_ms))
+                continue;
+            if (hipSetDevice(p->cfg.device) == hipSuccess)
+                (void)resident_cancel_locked(p);
+            else
+                (void)hipGetLastError();
+        }
+    }
+}
+void resident_register(pipe_hip_processor *p)
+{
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    static bool hooked = false;
+    if (!hooked) {
+        hooked = true;
+        std::atexit(resident_ring_all);
+        std::thread(resident_watchdog).detach();
+    }
+    g_resident.push_back(p);
+}
+void resident_unregister(pipe_hip_processor *p)
+{
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    for (size_t i = 0; i < g_resident.size(); ++i)
+        if (g_resident[i] == p) {
+            g_resident[i] = g_resident.back();
+            g_resident.pop_back();
+            break;
+        }
+}
+}  // namespace
+
+int pipe_hip_processor::enter()
+{
+    PH_TRY(select_device());
+    return resident_cancel(this);
+}
+
 pipe_hip_processor::~pipe_hip_processor()
 {
     if (cfg.buffer_size > 0)
         (void)hipSetDevice(cfg.device);
+    if (resident.mail.p) {
+        resident_unregister(this);  // (first: the watchdog then no longer sees the handle)
+        (void)resident_cancel(this);
+    }
     delete overlap;
     if (stream) {
         (void)hipStreamSynchronize(stream);
@@ -398,7 +605,7 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
         return PIPE_HIP_EINVAL;
     if (p->in_flight >= 2)
         return PIPE_HIP_ESTATE;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     const int slot = p->submit_slot;
     PH_TRY(p->ensure_staging(slot));
     pipe_hip_processor::Staging &g = p->stg[slot];
@@ -456,7 +663,7 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
 {
     if (p->in_flight < 1)
         return PIPE_HIP_ESTATE;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     pipe_hip_processor::Staging &g = p->stg[(p->submit_slot - p->in_flight) & 1];
     PH_HIP(hipEventSynchronize(g.done));
     p->in_flight -= 1;
@@ -544,25 +751,21 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
     // be the upload itself (one pass over the caller's rows, write-combined stores over PCIe) instead
     // of a copy into pinned memory plus a DMA.  PIPE_HIP_BAR_UPLOAD=0 keeps the DMA path.
     {
-        static const int large_bar = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) {
-                (void)hipGetLastError();
-                return 0;
-            }
-            return v;
-        }();
+        const BarInfo bi = bar_info(p->cfg.device);
         const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD");
-        c.bar = large_bar != 0 && !(e && e[0] == '0');
+        // default: where the device has a large BAR AND says where its HDP flush register is; without the
+        // register only on request (PIPE_HIP_BAR_UPLOAD=1: a platform whose host writes are coherent without it)
+        c.bar = bi.large_bar && (e ? e[0] != '0' : bi.hdp_flush != nullptr);
+        c.hdp_flush = bi.hdp_flush;
         if (c.bar) {
-            // ... and the staging buffer really is in this process's address space (the attribute is a
-            // device property; a platform that reports it without mapping allocations must not be
-            // written to): mincore fails with ENOMEM on an unmapped range and touches nothing
-            const long page = sysconf(_SC_PAGESIZE);
-            unsigned char vec = 0;
-            void *first = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(c.d_in) & ~(uintptr_t)(page - 1));
-            if (page <= 0 || mincore(first, (size_t)page, &vec) != 0)
-                c.bar = false;
+            // ... and the staging buffer really is writable in this process's address space (asked once per
+            // staging allocation)
+            if (ov.bar_checked != static_cast<const void *>(g.d_in.p) || ov.bar_checked_bytes != g.d_in.bytes) {
+                ov.bar_checked = g.d_in.p;
+                ov.bar_checked_bytes = g.d_in.bytes;
+                ov.bar_ok = host_writable(g.d_in.p, g.d_in.bytes);
+            }
+            c.bar = ov.bar_ok;
         }
     }
     c.trace = std::getenv("PIPE_HIP_OVERLAP_TRACE") != nullptr;  // debug: where a call's time goes
@@ -689,7 +892,7 @@ int pipe_hip_start(pipe_hip_processor *p)
 {
     if (!p)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     PH_TRY(p->drain());  // a restarted pipe drops whatever was in flight, on whichever stream
     p->in_flight = 0;
     PH_TRY(p->start(p->stream));
@@ -703,7 +906,7 @@ int pipe_hip_start_lines(pipe_hip_processor *p, int32_t first, int32_t count)
         return PIPE_HIP_EINVAL;
     if (p->in_flight)
         return PIPE_HIP_ESTATE;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     PH_TRY(p->drain());
     PH_TRY(p->start_lines(first, count, p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
@@ -714,7 +917,7 @@ int pipe_hip_flush(pipe_hip_processor *p)
 {
     if (!p)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     PH_TRY(p->drain());
     p->in_flight = 0;
     return p->poll_error();
@@ -727,6 +930,7 @@ int pipe_hip_destroy(pipe_hip_processor *p)
     if (p->owned_by_chain)
         return PIPE_HIP_EINVAL;
     (void)hipSetDevice(p->cfg.device);
+    resident_cancel_device(p->cfg.device);  // (no queue of ours may wait for a doorbell across the device-wide wait)
     (void)hipDeviceSynchronize();
     delete p;
     return PIPE_HIP_OK;
@@ -760,7 +964,7 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         const size_t row_in = es * (size_t)in_frames * (size_t)p->cfg.channels;
         const size_t row_out = es * (size_t)in_frames * (size_t)p->out_channels();
         if (row_in * (size_t)p->cfg.lines >= overlap_min_bytes()) {
-            PH_TRY(p->select_device());
+            PH_TRY(p->enter());
             PH_TRY(p->ensure_staging());
             const char *ib = static_cast<const char *>(in);
             char *ob = static_cast<char *>(out);
@@ -771,6 +975,32 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
                 *out_frames = in_frames;
             return p->poll_error();
         }
+    }
+    if (p->resident.enabled && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
+        in_frames <= out_cap_frames) {
+        // The buffer's work is already on the device, behind the doorbell (queued while the last buffer ran):
+        // copy in, ring, queue the NEXT buffer's work while this one runs, spin on the completion word.
+        pipe_hip_processor::Resident &R = p->resident;
+        PH_TRY(p->select_device());
+        std::lock_guard<std::mutex> lk(R.mu);  // (the watchdog keeps its hands off until the result is out)
+        if (R.pending.load() && R.frames != in_frames)
+            PH_TRY(resident_cancel_locked(p));  // (a short buffer: pipe.go:441-443)
+        if (!R.pending.load())
+            PH_TRY(resident_arm(p, in_frames));  // the first call, or the one after a cancellation
+        pipe_hip_processor::Staging &g = p->stg[0];
+        const size_t es = dtype_size(p->cfg.dtype);
+        std::memcpy(g.h_in.p, in, es * (size_t)in_frames * (size_t)p->cfg.channels * (size_t)p->cfg.lines);
+        const unsigned k = R.seq;
+        const int64_t produced = R.out_frames;
+        __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
+        R.pending.store(false);
+        const int rc_next = resident_arm(p, in_frames);
+        PH_TRY(resident_wait(p, k));
+        std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
+        if (out_frames)
+            *out_frames = (int32_t)produced;
+        PH_TRY(rc_next);
+        return p->poll_error();
     }
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
     return collect_impl(p, out, out_cap_frames, out_frames);
@@ -848,7 +1078,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
         return PIPE_HIP_EINVAL;
     if (p->in_flight)
         return PIPE_HIP_ESTATE;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     PH_TRY(p->ensure_staging());
     const int L = p->cfg.lines;
     std::vector<LineRun> runs;
@@ -916,7 +1146,7 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
         return PIPE_HIP_EINVAL;
     if (p->in_flight)
         return PIPE_HIP_ESTATE;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     PH_TRY(p->ensure_staging());
     const int L = p->cfg.lines;
     const size_t es = dtype_size(p->cfg.dtype);
@@ -968,7 +1198,7 @@ int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t 
         return PIPE_HIP_EINVAL;
     if (p->single_input() || (frames > 0 && !out))
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     const size_t es = dtype_size(p->cfg.dtype);
     const size_t one = es * (size_t)p->cfg.lines * (size_t)frames * (size_t)p->cfg.channels;
     const size_t cap = es * (size_t)p->cfg.lines * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels;
@@ -1004,7 +1234,32 @@ int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *value
 {
     if (!p || !values || count < 1)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
+    if (param == PIPE_HIP_PARAM_RESIDENT) {
+        if (count != 1)
+            return PIPE_HIP_EINVAL;
+        pipe_hip_processor::Resident &R = p->resident;
+        if (values[0] == 0.0) {
+            R.enabled = false;  // (enter() has run what was queued)
+            return PIPE_HIP_OK;
+        }
+        // one Line, a fixed-rate single-input stage that can take a queued launch back, buffers small enough
+        // for the zero-copy staging path
+        const size_t bytes = dtype_size(p->cfg.dtype) * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels * (size_t)p->cfg.lines;
+        if (p->owned_by_chain || !p->armable() || !p->fixed_rate() || !p->single_input() || bytes > ((size_t)1 << 20) || p->in_flight)
+            return PIPE_HIP_EINVAL;
+        PH_TRY(p->ensure_staging(0));
+        if (!p->stg[0].hd_in || !p->stg[0].hd_out)
+            return PIPE_HIP_EINVAL;
+        if (!R.mail.p) {
+            PH_TRY(R.mail.alloc(128, true));
+            std::memset(R.mail.p, 0, 128);
+            resident_register(p);
+        }
+        R.enabled = true;
+        R.idle_ms = values[0] > 1.0 ? (int)values[0] : 250;  // (a value above 1: the idle limit in milliseconds)
+        return PIPE_HIP_OK;
+    }
     return p->set_param(param, values, count);
 }
 
@@ -1013,7 +1268,7 @@ int pipe_hip_chain_set_param(pipe_hip_processor *p, int32_t stage, int32_t param
 {
     if (!p || !values || count < 1)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     return p->set_stage_param(stage, param, values, count);
 }
 
@@ -1026,7 +1281,7 @@ int pipe_hip_process_batch(pipe_hip_processor *p, const void *d_in, void *d_out,
         return PIPE_HIP_EINVAL;
     if (!p->fixed_rate() || !p->single_input())
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
     p->batch_stream = s;
     return p->run(d_in, p->cfg.dtype, d_out, p->cfg.dtype, frames_per_line, s);
@@ -1039,7 +1294,7 @@ int pipe_hip_resample_batch(pipe_hip_processor *p, const void *d_in, int64_t in_
         return PIPE_HIP_EINVAL;
     if (in_frames_per_line > (int64_t)p->cfg.buffer_size * p->cfg.max_batch)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
     p->batch_stream = s;
     return p->run_var(d_in, p->cfg.dtype, in_frames_per_line, d_out, p->cfg.dtype, out_cap_frames,
@@ -1051,7 +1306,7 @@ int pipe_hip_mix_batch(pipe_hip_processor *p, const void *const *d_ins, int32_t 
 {
     if (!p || !d_ins || !d_out || frames_per_line < 0 || p->single_input())
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
     p->batch_stream = s;
     return mix_run(p, d_ins, n_inputs, d_out, frames_per_line, s);
@@ -1069,7 +1324,7 @@ int pipe_hip_kernel_time(pipe_hip_processor *p, double *total_ms, int64_t *launc
 {
     if (!p)
         return PIPE_HIP_EINVAL;
-    PH_TRY(p->select_device());
+    PH_TRY(p->enter());
     return p->timer.collect(total_ms, launches, reset != 0);
 }
 

@@ -111,6 +111,20 @@ public:
         last_kernel = stages.empty() ? "" : stages[0]->last_kernel;
         return PIPE_HIP_OK;
     }
+    // PIPE_HIP_PARAM_RESIDENT: a chain of stages each of which can take a queued launch back (FIR, gain); per-buffer
+    // calls never take the fused kernel, whose state lives in tagged slots
+    bool armable() const override
+    {
+        for (auto &st : stages)
+            if (!st->armable())
+                return false;
+        return !stages.empty();
+    }
+    void rollback_launch() override
+    {
+        for (auto &st : stages)
+            st->rollback_launch();
+    }
     void set_window(int first, int count) override
     {
         pipe_hip_processor::set_window(first, count);

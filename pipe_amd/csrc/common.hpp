@@ -4,6 +4,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <mutex>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -65,12 +69,14 @@ struct DevBuf {
 struct PinnedBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    int alloc(size_t n)
+    // coherent: fine-grained memory whose words the host and a RUNNING device queue may hand back and forth
+    // (doorbell / completion words); the default serves staging buffers read and written by whole launches
+    int alloc(size_t n, bool coherent = false)
     {
         release();
         if (n == 0)
             n = 16;
-        PH_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+        PH_HIP(hipHostMalloc(&p, n, coherent ? (hipHostMallocCoherent | hipHostMallocMapped) : hipHostMallocDefault));
         bytes = n;
         return PIPE_HIP_OK;
     }
@@ -302,9 +308,38 @@ struct pipe_hip_processor {
     // device-side failures that cannot be reported by the asynchronous call that caused them
     virtual int poll_error() { return PIPE_HIP_OK; }
 
+    // ---- the per-buffer path with the next call's work queued ahead of it (PIPE_HIP_PARAM_RESIDENT) ----
+    // armable(): a run() that has been queued can be executed on stale input and its effect dropped --
+    // the stage is stateless, or its state is double-buffered and rollback_launch() points it back at the
+    // half the dropped launch did not write.  Stages that update state in place answer false.
+    virtual bool armable() const { return false; }
+    virtual void rollback_launch() {}
+    struct Resident {
+        bool enabled = false;
+        pipehip::PinnedBuf mail;      // doorbell word at +0, completion word at +64 (coherent pinned memory)
+        unsigned seq = 0;             // the sequence number the queued work waits for
+        std::atomic<bool> pending{false};  // work is queued behind `seq`
+        int32_t frames = 0;           // ... for a buffer of this many frames
+        int64_t out_frames = 0;
+        // A queue that waits for a doorbell also holds up every device-wide synchronisation of the process
+        // (hipDeviceSynchronize: torch.cuda.synchronize(), a handle's destruction).  So queued work does not
+        // outlive `idle_ms` without a call: a watchdog thread of the library then runs it on stale input and takes
+        // it back, exactly as a mutation would (the next call queues afresh).  `mu` is held by whoever touches
+        // the doorbell, the queued work or the staging buffers: the fast path for its whole length, the
+        // watchdog, every other entry while it cancels.
+        std::mutex mu;
+        std::chrono::steady_clock::time_point armed_at{};
+        int idle_ms = 250;
+        unsigned *bell() const { return static_cast<unsigned *>(mail.p); }
+        unsigned *done() const { return static_cast<unsigned *>(mail.p) + 16; }
+    };
+    Resident resident;
+
     int init_common(const pipe_hip_config *c);
     int ensure_staging(int slot = 0);
     int select_device() const;
+    // every entry but the resident fast path: the handle's device, and nothing queued behind a doorbell
+    int enter();
 };
 
 namespace pipehip {

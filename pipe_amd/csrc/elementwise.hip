@@ -169,6 +169,7 @@ public:
     double gain = 1.0;
     int start(hipStream_t) override { return PIPE_HIP_OK; }
     int start_lines(int, int, hipStream_t) override { return PIPE_HIP_OK; }  // stateless
+    bool armable() const override { return true; }  // (stateless: a queued launch that is dropped leaves nothing behind)
     int set_param(int32_t param, const double *values, int32_t count) override
     {
         if (param != PIPE_HIP_PARAM_GAIN || count != 1 || !values)

@@ -625,6 +625,15 @@ public:
         return flip_history(s);
     }
 
+    // PIPE_HIP_PARAM_RESIDENT: a queued launch wrote the OTHER half of the history double buffer and
+    // flip_history() pointed the stage at it; taking the launch back is pointing it at the old half again
+    bool armable() const override { return true; }
+    void rollback_launch() override
+    {
+        if (H_ > 0)
+            cur_hist_ ^= 1;
+    }
+
     bool fuse_view_fir(FirFuseView *v, hipStream_t s, bool prepare) override
     {
         if (!ols_ || windowed())

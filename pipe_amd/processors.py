@@ -263,6 +263,12 @@ class Processor:
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         L.check(L.lib().pipe_hip_set_param(self._h, param, _dptr(v), v.size), "set_param")
 
+    def set_resident(self, on: bool = True):
+        """PIPE_HIP_PARAM_RESIDENT: keep the next buffer's work queued on the device behind a doorbell, so that
+        process() costs no kernel launch and no completion event (stages that can take a queued launch back:
+        gain, FIR, chains of those; one buffer of at most 1 MiB)."""
+        self._set_param(L.PARAM_RESIDENT, [1.0 if on else 0.0])
+
 
 class Gain(Processor):
     def __init__(self, gain: float, buffer_size: int, channels: int, **kw):

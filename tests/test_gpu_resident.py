@@ -1,0 +1,142 @@
+"""PIPE_HIP_PARAM_RESIDENT: pipe_hip_process with the next buffer's work queued on the device ahead of its call
+(behind a doorbell word the host rings; run.go:198-224's loop moved next to the data, depth per link still
+fitting.go:56-60's one buffer).  Everything the plain per-buffer path guarantees must hold through this entry
+too: bit for bit the oracle, mutations seen by the next buffer, short buffers, restarts."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import _lib as L
+from pipe_amd import processors as P
+from pipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+F, C, N = 4096, 2, 256
+
+
+def stream(seed, buffers, frames=F, channels=C):
+    return synth.samples(synth.line_seed(seed), 0, buffers * frames * channels).reshape(buffers, frames, channels)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fir_stream_is_the_oracles_bit_for_bit(dtype):
+    taps = synth.fir_lowpass_taps(N)
+    x = stream(3, 12)
+    with P.Fir(taps, F, C, dtype=dtype) as fir, P.Fir(taps, F, C, dtype=dtype) as plain:
+        fir.start()
+        plain.start()
+        fir.set_resident(True)
+        ref = O.Fir(taps, C)
+        for k in range(12):
+            frames = F if k != 7 and k != 11 else (1000 if k == 7 else 17)  # short buffers in the middle and at the end
+            xin = x[k, :frames].astype(dtype)
+            got = fir.process(xin)
+            want = ref.process(x[k, :frames].astype(dtype).astype(np.float64)).reshape(frames, C).astype(dtype)
+            assert got.shape == want.shape and np.array_equal(got, want), f"buffer {k}"
+            assert np.array_equal(got, plain.process(xin))
+        fir.flush()
+
+
+def test_a_taps_mutation_reaches_the_next_buffer_and_no_other():
+    taps = synth.fir_lowpass_taps(N)
+    taps2 = taps[::-1].copy() * 0.5
+    x = stream(4, 8).astype(np.float32)
+    with P.Fir(taps, F, C, dtype=np.float32) as fir:
+        fir.start()
+        fir.set_resident(True)
+        ref = O.Fir(taps, C)
+        for k in range(8):
+            if k == 3:  # the queued launch of buffer 3 was made with the old taps: it is run and dropped
+                fir.set_taps(taps2)
+                ref.set_taps(taps2)
+            got = fir.process(x[k])
+            want = ref.process(x[k].astype(np.float64)).reshape(F, C).astype(np.float32)
+            assert np.array_equal(got, want), f"buffer {k}"
+
+
+def test_gain_and_its_mutation():
+    x = stream(5, 6).astype(np.float32)
+    with P.Gain(0.25, F, C, dtype=np.float32) as g:
+        g.start()
+        g.set_resident(True)
+        for k in range(6):
+            if k == 4:
+                g.set_gain(-3.0)
+            want = (x[k].astype(np.float64) * (0.25 if k < 4 else -3.0)).astype(np.float32)
+            assert np.array_equal(g.process(x[k]), want)
+
+
+def test_chain_of_fir_and_gain_restart_and_other_entries():
+    import torch
+    taps = synth.fir_lowpass_taps(64)
+    x = stream(6, 10).astype(np.float32)
+    with P.Chain([P.Fir(taps, F, C, dtype=np.float32), P.Gain(0.5, F, C, dtype=np.float32)]) as ch:
+        ch.start()
+        ch.set_resident(True)
+        ref = O.Fir(taps, C)
+        for k in range(10):
+            if k == 4:  # StartFunc in the middle: the queued launch is taken back, state is silence again
+                ch.start()
+                ref = O.Fir(taps, C)
+            if k == 6:  # a device-resident batch call on the same handle between two buffers
+                d_in = torch.from_numpy(x[k].reshape(-1)).cuda()
+                d_out = torch.empty_like(d_in)
+                ch.process_batch(d_in, d_out, F)
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy().reshape(F, C)
+            else:
+                got = ch.process(x[k])
+            want = (ref.process(x[k].astype(np.float64)).reshape(F, C) * 0.5).astype(np.float32)
+            assert np.array_equal(got, want), f"buffer {k}"
+        ch.set_resident(False)
+        got = ch.process(x[0])
+        want = (ref.process(x[0].astype(np.float64)).reshape(F, C) * 0.5).astype(np.float32)
+        assert np.array_equal(got, want)
+
+
+def test_stages_with_in_place_state_and_many_lines_are_turned_away():
+    with P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=np.float32) as bq:
+        bq.start()
+        with pytest.raises(L.PipeHipError):
+            bq.set_resident(True)
+    with P.Gain(0.5, 4096, 8, dtype=np.float32, lines=512) as g:  # 64 MiB a buffer: not the zero-copy path
+        g.start()
+        with pytest.raises(L.PipeHipError):
+            g.set_resident(True)
+
+
+def test_a_handle_destroyed_with_work_queued_leaves_nothing_waiting():
+    x = stream(7, 2).astype(np.float32)
+    for _ in range(3):
+        g = P.Gain(2.0, F, C, dtype=np.float32)
+        g.start()
+        g.set_resident(True)
+        assert np.array_equal(g.process(x[0]), (x[0] * 2.0).astype(np.float32))
+        g.close()  # a launch for the next buffer is queued behind the doorbell right now
+    with P.Gain(2.0, F, C, dtype=np.float32) as g2:  # the device still answers
+        g2.start()
+        assert np.array_equal(g2.process(x[1]), (x[1] * 2.0).astype(np.float32))
+
+
+def test_queued_work_does_not_hold_a_device_wide_synchronisation_for_ever():
+    """A queue waiting for a doorbell holds up hipDeviceSynchronize; the library's watchdog takes queued work back
+    when no call has come for the idle limit (here 60 ms), and the stream goes on bit for bit afterwards."""
+    import time
+    import torch
+    taps = synth.fir_lowpass_taps(N)
+    x = stream(8, 4).astype(np.float32)
+    with P.Fir(taps, F, C, dtype=np.float32) as fir:
+        fir.start()
+        fir._set_param(L.PARAM_RESIDENT, [60.0])
+        ref = O.Fir(taps, C)
+        for k in range(4):
+            got = fir.process(x[k])
+            want = ref.process(x[k].astype(np.float64)).reshape(F, C).astype(np.float32)
+            assert np.array_equal(got, want), f"buffer {k}"
+            if k == 1:
+                t0 = time.perf_counter()
+                torch.cuda.synchronize()  # the next buffer's work is queued behind the doorbell right now
+                assert time.perf_counter() - t0 < 2.0
+            if k == 2:
+                time.sleep(0.2)  # the watchdog has taken the queued work back: the next call queues afresh
