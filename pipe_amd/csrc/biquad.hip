@@ -1330,7 +1330,13 @@ public:
         }
         // up to 8 channels and one or two sections: the LDS-tiled form (coalesced; the lane walks are not)
         const int tc = cfg.channels, tspc = tc <= 8 ? kTileThreads / tc : 0;
-        const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
+        // A call that is too small for the thresholds above but LONG -- one pipe buffer of a Line or two per
+        // ProcessFunc call -- is where the ordered recurrence hurts most: it is one wave's issue, 22 ns a frame
+        // whatever the chip (4096 x 2: 90 us, a host core does it in 10).  The tile form takes a float32 buffer of
+        // kTileLatencyFrames or more frames in one short launch (4096 x 2: 12.8 us); PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES
+        // set in the environment is the only rule when it is there.
+        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && a.nseries <= kTileLatencySeries;
+        const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
                            frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
         // 3 or 4 sections: the tile kernel holds two, so two tile passes over the halves of the cascade with a float64
@@ -1967,6 +1973,8 @@ private:
     size_t state_bytes_ = 0;
     bool exact_ = false;
     const bool env_exact_ = std::getenv("PIPE_HIP_BIQUAD_EXACT") != nullptr;
+    static constexpr int64_t kTileLatencyFrames = 1024, kTileLatencySeries = 64;
+    const bool seg_min_from_env_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES") != nullptr;
     int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))
                                          : (int64_t)1 << 20;

@@ -329,3 +329,29 @@ def test_sections_that_are_not_strictly_stable_keep_the_ordered_recurrence(monke
         p.process_batch(d_in, d_out, F)
         torch.cuda.synchronize()
         assert "chain_fused" not in p.kernel_name(), p.kernel_name()
+
+
+@pytest.mark.parametrize("sections", [1, 2])
+def test_one_float32_pipe_buffer_per_call_takes_the_tile_form(sections):
+    """pipe_hip_process, one 4096 x 2 float32 buffer a call (called at pipe.go:438): the ordered recurrence is one
+    wave's issue (90 us a buffer); a float32 buffer of 1024 frames or more of few series takes the tile form in one
+    short launch, under this file's bound; float64 buffers and PIPE_HIP_PARAM_EXACT keep the ordered form."""
+    q = coeffs(sections)
+    F, C, B = 4096, 2, 6
+    x = synth.samples(synth.line_seed(11), 0, B * F * C, np.float32).reshape(B, F, C)
+    want = oracle(q, x.reshape(1, B * F, C))[0].reshape(B, F, C)
+    with P.Biquad(q, F, C, dtype=np.float32) as bq, P.Biquad(q, F, C, dtype=np.float32) as ex, \
+            P.Biquad(q, F, C, dtype=np.float64) as b64:
+        for p in (bq, ex, b64):
+            p.start()
+        ex.set_exact(True)
+        got = np.stack([bq.process(x[k] if k < B - 1 else x[k, :1500]) for k in range(B)][:-1])
+        assert bq.kernel_name().startswith("biquad_tile_kernel"), bq.kernel_name()
+        w32 = want[:B - 1].astype(np.float32)
+        err = np.abs(got.astype(np.float64) - w32.astype(np.float64)) / relaxed_ulp(q, want[:B - 1].reshape(1, -1, C)).reshape(B - 1, F, C)
+        assert err.max() <= 1.0, err.max()
+        assert (got != w32).sum() <= max(4, got.size // 100000)
+        for k in range(B - 1):
+            assert np.array_equal(ex.process(x[k]), w32[k])
+            assert np.array_equal(b64.process(x[k].astype(np.float64)), want[k])
+        assert not ex.kernel_name().startswith("biquad_tile_kernel") and not b64.kernel_name().startswith("biquad_tile_kernel")
