@@ -84,27 +84,34 @@ typedef enum pipe_hip_param {
                                   the samples of a 1024-frame window / a segment, so a NaN or Inf
                                   input reaches more outputs than in the ordered form: set this
                                   for streams that may carry non-finite samples. */
-    PIPE_HIP_PARAM_RESIDENT = 4 /* 1 value: != 0 keeps the NEXT pipe buffer's work queued on the device ahead of
-                                  its call (run.go:198-224's loop, one buffer per pipe_hip_process, moved next
-                                  to the data): behind a wait on a doorbell word in pinned host memory sit the
-                                  stage's kernels and a store to a completion word.  pipe_hip_process then
-                                  copies the buffer into the pinned staging area, rings the doorbell, queues
-                                  the work of the call after this one while the device runs, and spins on the
-                                  completion word -- no kernel launch and no completion event on the call's
-                                  path (4096 x 2 FIR-256: 24-26 us -> see DESIGN.md).  Depth per link stays
-                                  fitting.go:56-60's: one buffer in the stage at a time, results bit for bit
-                                  those of the plain path.  Opt-in per handle; stages whose state a queued
-                                  launch cannot be taken back from (biquad, resampler) and handles of many
-                                  Lines answer PIPE_HIP_EINVAL.  Idle cost: the queue's command processor
-                                  polls one word; no compute unit is held.  The queued work assumes the
-                                  frame count of the last call: a call that brings another count, a
-                                  parameter mutation or any other entry on the handle first runs the queued
-                                  work on stale input and discards it (one wasted round trip).  A queue that
-                                  waits for a doorbell holds up device-wide synchronisations of the process
-                                  (hipDeviceSynchronize), so queued work is also discarded -- by a watchdog
-                                  thread of the library -- when no call has come for 250 ms (a value above 1:
-                                  that many milliseconds); pipe_hip_destroy of any handle discards what is
-                                  queued on its device before it waits for the device. */
+    PIPE_HIP_PARAM_RESIDENT = 4, /* 1 value: != 0 keeps the NEXT pipe buffer's work queued on the device ahead of
+                                   its call (run.go:198-224's loop, one buffer per pipe_hip_process, moved next
+                                   to the data): behind a wait on a doorbell word in pinned host memory sit the
+                                   stage's kernels and a store to a completion word.  pipe_hip_process then
+                                   copies the buffer into the pinned staging area, rings the doorbell, queues
+                                   the work of the call after this one while the device runs, and spins on the
+                                   completion word -- no kernel launch and no completion event on the call's
+                                   path (4096 x 2 FIR-256: 24-26 us -> see DESIGN.md).  Depth per link stays
+                                   fitting.go:56-60's: one buffer in the stage at a time, results bit for bit
+                                   those of the plain path.  Opt-in per handle; stages whose state a queued
+                                   launch cannot be taken back from (biquad, resampler) and handles of many
+                                   Lines answer PIPE_HIP_EINVAL.  Idle cost: the queue's command processor
+                                   polls one word; no compute unit is held.  The queued work assumes the
+                                   frame count of the last call: a call that brings another count, a
+                                   parameter mutation or any other entry on the handle first runs the queued
+                                   work on stale input and discards it (one wasted round trip).  A queue that
+                                   waits for a doorbell holds up device-wide synchronisations of the process
+                                   (hipDeviceSynchronize), so queued work is also discarded -- by a watchdog
+                                   thread of the library -- when no call has come for 250 ms (a value above 1:
+                                   that many milliseconds); pipe_hip_destroy of any handle discards what is
+                                   queued on its device before it waits for the device. */
+    PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
+                                  biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
+                                  up after limit_us -- the failure a preempted predecessor tile causes.  A
+                                  synchronous entry then puts the state back and runs the call again in a form
+                                  without look-back (the result is the stream's, the status OK); an asynchronous
+                                  pipe_hip_process_batch reports PIPE_HIP_EHIP at the next synchronous entry with
+                                  the stream's state as it was BEFORE the failed batch.  For tests. */
 } pipe_hip_param;
 
 /* Opaque Processor handle: the state a Go closure would capture. */

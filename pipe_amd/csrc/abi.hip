@@ -290,6 +290,7 @@ struct pipe_hip_processor::Overlap {
         p->set_window(c.first + l0, (c.first + l0 == 0 && n == p->cfg.lines) ? 0 : n);
         int64_t produced = c.frames;
         PH_TRY(p->run_var(c.d_in + io, p->cfg.dtype, c.frames, c.d_out + oo, p->cfg.dtype, c.frames, &produced, p->stream));
+        PH_TRY(p->settle(p->stream));
         PH_HIP(hipEventRecord(done, p->stream));
         PH_HIP(hipStreamWaitEvent(s_out, done, 0));
         PH_HIP(hipMemcpyAsync(c.h_out + oo, c.d_out + oo, c.row_out * (size_t)n, hipMemcpyDeviceToHost, s_out));
@@ -641,10 +642,12 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
         recorded = p->completion == nullptr;
         p->completion = nullptr;
         PH_TRY(rc);
+        PH_TRY(p->settle(p->stream));  // (a look-back form that failed is run again before the buffer is handed back)
     } else {
         if (in_b)
             PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
         PH_TRY(p->run_var(g.d_in.p, p->cfg.dtype, in_frames, g.d_out.p, p->cfg.dtype, cap, &out_frames, p->stream));
+        PH_TRY(p->settle(p->stream));
         const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
                              (size_t)p->out_channels();
         if (out_b)
@@ -1122,6 +1125,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
                               row_in * (size_t)r.count, hipMemcpyHostToDevice, p->stream));
         PH_TRY(p->run_var(static_cast<char *>(p->stg[0].d_in.p) + r.in_off, p->cfg.dtype, r.frames,
                           static_cast<char *>(p->stg[0].d_out.p) + r.out_off, p->cfg.dtype, r.frames, &produced, p->stream));
+        PH_TRY(p->settle(p->stream));
         PH_HIP(hipMemcpyAsync(static_cast<char *>(p->stg[0].h_out.p) + r.out_off, static_cast<char *>(p->stg[0].d_out.p) + r.out_off,
                               row_out * (size_t)r.count, hipMemcpyDeviceToHost, p->stream));
     }
@@ -1184,6 +1188,7 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
         PH_TRY(launch_gather_rows(tin + r.first, win + r.first, din, (int)((size_t)r.frames * fb_in / 8), r.count,
                                   p->stream));
         PH_TRY(p->run_var(din, p->cfg.dtype, r.frames, dout, p->cfg.dtype, r.frames, &produced, p->stream));
+        PH_TRY(p->settle(p->stream));
         PH_TRY(launch_scatter_rows(tout + r.first, wout + r.first, dout, (int)((size_t)r.frames * fb_out / 8), r.count,
                                    p->stream));
     }

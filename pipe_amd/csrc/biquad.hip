@@ -33,6 +33,7 @@
 // sits within ~1e-15 of a rounding boundary (then: the neighbouring float32, 1 ulp) -- the same
 // contract as the FIR's overlap-save form ("the one tolerance").
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <cstring>
@@ -321,7 +322,22 @@ struct BiquadLookArgs {
     int *err;                         // host-visible: a look-back that gave up
     unsigned epoch;
     int nl;
+    double *state_bak;                // [nseries][2 S]: the carried state as tile 0 read it (what a failed launch is taken back to)
+    unsigned long long spin_ticks;    // a wait for a predecessor's record gives up after this many s_memtime ticks
+    int withhold;                     // debug (PIPE_HIP_PARAM_DEBUG): tiles of this index publish nothing (-1: none)
 };
+// (bounded by TIME: a preempted predecessor may be away for milliseconds; every 256th poll reads the clock)
+__device__ __forceinline__ bool look_expired(unsigned &spins, unsigned long long &t0, unsigned long long limit)
+{
+    if ((++spins & 255u) != 0u)
+        return false;
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if (t0 == 0ull) {
+        t0 = now;
+        return false;
+    }
+    return now - t0 > limit;
+}
 __device__ __forceinline__ void look_publish(unsigned long long *p, const double *v, int n, unsigned epoch)
 {
     for (int i = 0; i < n; ++i) {
@@ -559,16 +575,20 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 for (int j = 0; j < N; ++j)
                     P[i][j] = i == j ? 1.0 : 0.0;
             }
-            if (full && tile + 1 < tiles_per_line)
+            const bool held = lk.withhold >= 0 && tile == lk.withhold;  // (debug: this tile's records never show up)
+            if (full && tile + 1 < tiles_per_line && !held)
                 look_publish(lk.aggr + slot, zk, N, lk.epoch);
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             for (int k = tile - 1;;) {
                 double v[N];
                 bool last = false, got = false;
                 if (k < 0) {  // (tile 0 only: see below)
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
+                    for (int i = 0; i < N; ++i) {
                         v[i] = a.state[series * a.sstride + a.soff + i];
+                        lk.state_bak[series * N + i] = v[i];  // (what a launch that fails is taken back to)
+                    }
                     last = got = true;
                 } else {
                     // tile 0 is asked for its TRUE end state only: it alone reads the series' carried state, and the
@@ -615,13 +635,13 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                     spins = 0;
                 } else {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                    if (look_expired(spins, spin_t0, lk.spin_ticks)) {  // seconds: something is wrong; give up loudly
                         *lk.err = 1;
                         break;
                     }
                 }
             }
-            if (full && tile + 1 < tiles_per_line) {
+            if (full && tile + 1 < tiles_per_line && !held) {
                 double e[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -678,21 +698,26 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         if constexpr (MODE == kSegSingle) {
             // the series' state after the call: with the lane that walked the Line's last frame
             if (active && tile + 1 == tiles_per_line && g == ((nreal - 1) >> kSegLog)) {
+                bool tile0_read = true;
                 if (tiles_per_line > 1) {  // not before tile 0 has read the state this overwrites
                     double v[N];
                     unsigned spins = 0;
+                    unsigned long long spin_t0 = 0;
                     while (!look_read<N>(lk.incl + series * (2 * N), v, lk.epoch)) {
                         __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 22)) {
+                        if (look_expired(spins, spin_t0, lk.spin_ticks)) {
                             *lk.err = 2;
+                            tile0_read = false;  // (the state stays what it was: the launch is taken back anyway)
                             break;
                         }
                     }
                 }
+                if (tile0_read) {
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    a.state[series * a.sstride + a.soff + 2 * k] = s1[k];
-                    a.state[series * a.sstride + a.soff + 2 * k + 1] = s2[k];
+                    for (int k = 0; k < NS; ++k) {
+                        a.state[series * a.sstride + a.soff + 2 * k] = s1[k];
+                        a.state[series * a.sstride + a.soff + 2 * k + 1] = s2[k];
+                    }
                 }
             }
         }
@@ -1246,6 +1271,16 @@ public:
             exact_ = values[0] != 0.0;
             return PIPE_HIP_OK;
         }
+        if (param == PIPE_HIP_PARAM_DEBUG && count == 2 && values) {  // the next tile launch fails on demand
+            debug_withhold_ = (int)values[0];
+            debug_limit_us_ = values[1];
+            for (auto &h : half_)
+                if (h) {
+                    h->debug_withhold_ = debug_withhold_;
+                    h->debug_limit_us_ = debug_limit_us_;
+                }
+            return PIPE_HIP_OK;
+        }
         if (param != PIPE_HIP_PARAM_COEFFS || count != 5 * S_ || !values)
             return PIPE_HIP_EINVAL;
         std::memcpy(q_.c, values, sizeof(double) * 5u * (size_t)S_);  // kernel argument
@@ -1255,6 +1290,46 @@ public:
         half_[1].reset();
         pw_seg_ = -1;
         return PIPE_HIP_OK;
+    }
+    // The one-pass tile launch of a synchronous entry: wait for it; if a look-back gave up, the carried state goes
+    // back to what tile 0 of every series read (the kernel keeps that copy) and the call runs again through the
+    // ordered recurrence, which waits for nobody.
+    int take_back(hipStream_t s)
+    {
+        const TileCall &c = last_tile_;
+        const size_t w = sizeof(double) * 2u * (size_t)S_;
+        PH_HIP(hipMemcpy2DAsync(c.state + c.soff, sizeof(double) * (size_t)c.sstride, state_bak_.p, w, w, (size_t)c.nseries,
+                                hipMemcpyDeviceToDevice, s));
+        return PIPE_HIP_OK;
+    }
+    int settle(hipStream_t s) override
+    {
+        bool failed = false;
+        for (int h = 0; h < 2; ++h)
+            if (half_[h] && half_[h]->last_tile_.valid) {  // (3 - 4 sections: the halves' launches)
+                PH_HIP(hipStreamSynchronize(s));
+                if (half_[h]->poll_error() != PIPE_HIP_OK)
+                    failed = true;
+            }
+        if (failed) {
+            for (int h = 0; h < 2; ++h)
+                if (half_[h] && half_[h]->last_tile_.valid) {
+                    PH_TRY(half_[h]->take_back(s));
+                    half_[h]->last_tile_.valid = false;
+                }
+            return rerun_ordered(split_call_, s);
+        }
+        if (!last_tile_.valid)
+            return PIPE_HIP_OK;
+        PH_HIP(hipStreamSynchronize(s));
+        if (poll_error() == PIPE_HIP_OK) {
+            last_tile_.valid = false;
+            return PIPE_HIP_OK;
+        }
+        PH_TRY(take_back(s));
+        const TileCall c = last_tile_;
+        last_tile_.valid = false;
+        return rerun_ordered(c, s);
     }
     // Precondition as for the fused chain's: the stream of the last launch has been synchronised.
     int poll_error() override
@@ -1268,10 +1343,43 @@ public:
         err_checked_ = true;
         if (*e != 0) {
             *e = 0;
+            // (an asynchronous call whose buffers are no longer ours: it cannot be run again from here, but the
+            // carried state can be what it was before it -- the caller may submit the batch again)
+            if (last_tile_.valid) {
+                (void)take_back(stream);
+                (void)hipStreamSynchronize(stream);
+                last_tile_.valid = false;
+            }
             return PIPE_HIP_EHIP;
         }
         return PIPE_HIP_OK;
     }
+    struct TileCall {
+        const void *d_in;
+        void *d_out;
+        int in_dtype, out_dtype;
+        int64_t frames;
+        double *state;
+        int sstride, soff, nseries;
+        bool valid;
+    };
+    TileCall last_tile_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false}, split_call_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false};
+    int rerun_ordered(const TileCall &c, hipStream_t s)
+    {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            std::fprintf(stderr, "pipe_hip: a tile biquad launch gave up waiting for a predecessor tile; the call was run again "
+                                 "through the ordered recurrence (further occurrences are not reported)\n");
+        }
+        ordered_once_ = true;
+        const int rc = run(c.d_in, c.in_dtype, c.d_out, c.out_dtype, c.frames, s);
+        ordered_once_ = false;
+        return rc;
+    }
+    bool ordered_once_ = false;
+    int debug_withhold_ = -1;
+    double debug_limit_us_ = 0.0;
     // a gain stage that directly follows this biquad in a chain is folded into the
     // store of the result (same float64 arithmetic as the separate stage)
     void set_post_gain(bool on, double g)
@@ -1309,7 +1417,8 @@ public:
         // time-segmented form: float32 results (or float64 intermediates of a float32 chain)
         // only, and only when the series alone cannot fill the machine
         // (the relaxed forms carry states through powers of the transition matrix: stable sections only)
-        const bool relaxed = !exact_ && !env_exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && relaxed_ok();
+        const bool relaxed = !exact_ && !env_exact_ && !ordered_once_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && relaxed_ok();
+        last_tile_.valid = false;
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
         bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
                          frames * a.nseries >= seg_min_samples_;
@@ -1453,6 +1562,8 @@ public:
 #undef PH_BT
 #undef PH_BT3
 #undef PH_BT4
+            if (single)  // (what settle() takes back and runs again if the look-back gives up)
+                last_tile_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true};
         } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
@@ -1808,6 +1919,14 @@ public:
         half_[0]->relaxed_f64_out = true;
         half_[1]->relaxed_f64_out = relaxed_f64_out;
         half_[1]->set_post_gain(has_gain_, gain_);
+        split_call_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true};
+        if (debug_withhold_ >= 0) {  // (halves made after the parameter was set)
+            for (int h = 0; h < 2; ++h) {
+                half_[h]->debug_withhold_ = debug_withhold_;
+                half_[h]->debug_limit_us_ = debug_limit_us_;
+            }
+            debug_withhold_ = -1;
+        }
         PH_TRY(half_[0]->run(d_in, in_dtype, mid_.p, PIPE_HIP_F64, frames, s));
         PH_TRY(half_[1]->run(mid_.p, PIPE_HIP_F64, d_out, out_dtype, frames, s));
         if (!direct) {
@@ -1887,6 +2006,18 @@ public:
         lk->err = err_dev_;
         lk->epoch = e;
         lk->nl = nl;
+        const size_t bak = sizeof(double) * (size_t)cfg.lines * (size_t)cfg.channels * (size_t)n;
+        if (state_bak_.bytes < bak)
+            PH_TRY(state_bak_.alloc(bak));
+        lk->state_bak = static_cast<double *>(state_bak_.p);
+        // ~4 s of the shader clock: a predecessor that a context switch took away is back long before that
+        lk->spin_ticks = 1ull << 33;
+        lk->withhold = -1;
+        if (debug_withhold_ >= 0) {
+            lk->withhold = debug_withhold_;
+            lk->spin_ticks = (unsigned long long)(debug_limit_us_ * 2000.0);  // (~2 ticks a nanosecond)
+            debug_withhold_ = -1;
+        }
         err_checked_ = false;
         return PIPE_HIP_OK;
     }
@@ -1994,7 +2125,7 @@ private:
     // (3 sections, 16.7 M samples: 1 Line x 2 ch 113 Gsamples/s against the lane walk's 12, 64 x 2 ch 120 against 48,
     // 2048 x 2 ch even; 512 x 8 ch 127 against 218)
     static constexpr int64_t kSplitMaxSeries = 2048;
-    DevBuf look_, ticket_, tab_;
+    DevBuf look_, ticket_, tab_, state_bak_;
     PinnedBuf err_;
     int *err_dev_ = nullptr;
     bool err_checked_ = true;

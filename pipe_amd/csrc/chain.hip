@@ -4,6 +4,7 @@
 // Only the first stage reads, and only the last stage writes, buffers of the
 // handle's I/O dtype -- so a float32 chain rounds once, at the end, exactly like
 // `(float)` applied to the oracle's float64 chain.
+#include <cstdio>
 #include <cstdlib>
 
 #include "chain_fused.hpp"
@@ -51,7 +52,8 @@ public:
         const size_t ns = stages.size();
         // FIR -> biquad (-> gain) on float32 buffers, a call large enough for the overlap-save
         // form: ONE kernel, one read and one write of the buffers (chain_fused.hip)
-        if (fusable(d_in, in_dtype, d_out, out_dtype, frames)) {
+        last_fused_.valid = false;
+        if (!no_fuse_ && fusable(d_in, in_dtype, d_out, out_dtype, frames)) {
             FirFuseView fv{};
             BiquadFuseView bv{};
             double g = 1.0;
@@ -67,6 +69,7 @@ public:
                         return PIPE_HIP_EHIP;
                     PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, frames, cfg.channels, cfg.lines, s, &timer,
                                        &last_kernel));
+                    last_fused_ = FusedCall{d_in, d_out, in_dtype, out_dtype, frames, true};
                     return stages[0]->fuse_commit_fir(s);
                 }
             }
@@ -134,6 +137,8 @@ public:
     // a mutation addressed to the chain goes to the first stage that owns the parameter
     int set_param(int32_t param, const double *values, int32_t count) override
     {
+        if (param == PIPE_HIP_PARAM_DEBUG && count == 2)
+            return debug_fail_next((int)values[0], values[1]);
         if (param == PIPE_HIP_PARAM_EXACT) {  // applies to every stage that has a relaxed form
             int rc = PIPE_HIP_EINVAL;
             for (auto &st : stages)
@@ -146,9 +151,40 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
+    // the fused launch of a synchronous entry: wait for it, and if its look-back gave up run the call again staged
+    int settle(hipStream_t s) override
+    {
+        if (!fused_ || !last_fused_.valid) {
+            for (auto &st : stages)  // (the staged chain: a stage that ran a look-back form looks after itself --
+                PH_TRY(st->settle(s));  //  its input, the chain's float64 intermediate, is still there)
+            return PIPE_HIP_OK;
+        }
+        const FusedCall c = last_fused_;
+        last_fused_.valid = false;
+        PH_HIP(hipStreamSynchronize(s));
+        if (fused_->poll_error() == PIPE_HIP_OK)
+            return PIPE_HIP_OK;
+        PH_TRY(take_back(s));
+        static bool said = false;
+        if (!said) {
+            said = true;
+            std::fprintf(stderr, "pipe_hip: a fused chain launch gave up waiting for a predecessor tile; the call was run "
+                                 "again on the staged chain (further occurrences are not reported)\n");
+        }
+        no_fuse_ = true;
+        const int rc = run(c.d_in, c.in_dtype, c.d_out, c.out_dtype, c.frames, s);
+        no_fuse_ = false;
+        return rc;
+    }
     int poll_error() override
     {
         int rc = fused_ ? fused_->poll_error() : PIPE_HIP_OK;
+        if (rc != PIPE_HIP_OK && last_fused_.valid) {
+            // an asynchronous call (pipe_hip_process_batch) whose buffers are no longer ours: the call cannot be run
+            // again from here, but the stream's state can be what it was before it -- the caller may submit it again
+            last_fused_.valid = false;
+            (void)take_back(stream);
+        }
         for (auto &st : stages) {
             const int r = st->poll_error();
             rc = rc != PIPE_HIP_OK ? rc : r;
@@ -162,7 +198,34 @@ public:
         return stages[(size_t)stage]->set_param(param, values, count);
     }
 
+    // debug: {tile, limit in microseconds} -- the next fused launch fails the way a preempted predecessor tile
+    // would make it fail (tests/test_gpu_chain_fused.py)
+    int debug_fail_next(int tile, double limit_us)
+    {
+        if (!fused_)
+            fused_.reset(new fused::Plan());
+        fused_->debug_fail_next(tile, limit_us);
+        return PIPE_HIP_OK;
+    }
+
 private:
+    struct FusedCall {
+        const void *d_in;
+        void *d_out;
+        int in_dtype, out_dtype;
+        int64_t frames;
+        bool valid;
+    };
+    FusedCall last_fused_{nullptr, nullptr, 0, 0, 0, false};
+    bool no_fuse_ = false;
+    // the state of before the failed launch: the cascade's from the slot the launch did not write, the FIR's
+    // history from the half it did not write
+    int take_back(hipStream_t s)
+    {
+        PH_TRY(fused_->rollback(s));
+        stages[0]->rollback_launch();
+        return PIPE_HIP_OK;
+    }
     bool fusable(const void *d_in, int in_dtype, const void *d_out, int out_dtype, int64_t frames) const
     {
         if (!fused::Plan::enabled() || windowed() || frames <= 0 || !fused::Plan::launchable())

@@ -247,6 +247,8 @@ struct Plan::Impl {
     size_t rec_granules = 0;
     bool err_checked = true;
     hipStream_t last_stream = nullptr;
+    int debug_withhold = -1;       // the next launch only
+    double debug_limit_us = 0.0;
 };
 
 Plan::Plan() : impl_(new Impl) {}
@@ -454,6 +456,31 @@ int Plan::export_state(hipStream_t s)
 // the stage's own array has been reset (StartFunc): what the slots hold is void
 void Plan::drop_state() { impl_->in_slots = false; }
 
+int Plan::rollback(hipStream_t s)
+{
+    Impl &I = *impl_;
+    if (!I.in_slots)
+        return PIPE_HIP_OK;
+    // own_read takes the newer slot that is NOT tagged with the epoch it is given: given the failed launch's own
+    // epoch it skips whatever that launch wrote
+    if (I.S == 2)
+        hipLaunchKernelGGL(chain_state_export_kernel<2>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch);
+    else
+        hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch);
+    PH_HIP(hipGetLastError());
+    I.in_slots = false;
+    ++I.epoch;  // (the failed launch's tags stay behind in the records and slots: never reused)
+    return PIPE_HIP_OK;
+}
+
+void Plan::debug_fail_next(int tile, double limit_us)
+{
+    impl_->debug_withhold = tile;
+    impl_->debug_limit_us = limit_us;
+}
+
 template <int S, bool GENERAL, bool LOCAL>
 static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const void *hist, Args32 a, const FuseArgs &fa,
                   const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
@@ -632,6 +659,15 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     fa.seg_state = static_cast<double *>(I.seg_state.p);
     fa.mats = static_cast<const double *>(I.mats[I.cur_mats].p);
     fa.err = I.err_dev;
+    // a wait for a predecessor's record gives up after ~4 s of the shader clock (2^33 ticks): a predecessor that a
+    // context switch took away is back long before that; the caller then runs the call again on the staged chain
+    fa.spin_ticks = 1ull << 33;
+    fa.withhold = -1;
+    if (I.debug_withhold >= 0) {
+        fa.withhold = I.debug_withhold;
+        fa.spin_ticks = (unsigned long long)(I.debug_limit_us * 2000.0);  // (~2 ticks a nanosecond)
+        I.debug_withhold = -1;
+    }
 #ifdef PH_FUSE_PROF
     if (!I.prof.p)
         PH_TRY(I.prof.alloc(sizeof(unsigned long long) * (ols::kTlOffset + (size_t)ols::kTlEvents * ols::kTlUnits * kWaves32 * 4096)));

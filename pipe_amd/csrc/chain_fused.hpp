@@ -45,6 +45,13 @@ public:
     // (the stage's array was just reset).
     int export_state(hipStream_t s);
     void drop_state();
+    // After a launch whose look-back gave up (poll_error() said so): the cascade's state of BEFORE that launch back
+    // in the biquad stage's array (the launch wrote the slot with the older tag; the other still holds what it
+    // read).  The caller points the FIR stage back at its old history and runs the call again on the staged chain.
+    int rollback(hipStream_t s);
+    // debug (PIPE_HIP_PARAM_DEBUG): the next launch's tiles of index `tile` publish nothing, and a wait gives up
+    // after `limit_us` microseconds -- the failure a preempted predecessor would cause, on demand
+    void debug_fail_next(int tile, double limit_us);
 
 private:
     int prepare(const double *coeffs, int S, int ntaps, hipStream_t s);

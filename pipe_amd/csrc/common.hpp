@@ -307,6 +307,12 @@ struct pipe_hip_processor {
     virtual bool fuse_view_biquad(BiquadFuseView *) { return false; }
     // device-side failures that cannot be reported by the asynchronous call that caused them
     virtual int poll_error() { return PIPE_HIP_OK; }
+    // Called by the SYNCHRONOUS entries right behind run_var(), while the call's buffers are still theirs: a
+    // stage whose launch can fail on the device (the look-back forms: a predecessor tile that never shows up)
+    // waits for it here and, if it failed, puts its state back and runs the call again in a form that cannot --
+    // the reference aborts the whole run on a ProcessFunc error (pipe.go:438-440), and this one is not the
+    // stream's fault.  Everything else: nothing to do.
+    virtual int settle(hipStream_t) { return PIPE_HIP_OK; }
 
     // ---- the per-buffer path with the next call's work queued ahead of it (PIPE_HIP_PARAM_RESIDENT) ----
     // armable(): a run() that has been queued can be executed on stale input and its effect dropped --

@@ -109,6 +109,8 @@ struct FuseArgs {
                                  // Line's last frame (for chain_tail_kernel)
     const double *mats;          // the matrices above
     int *err;                    // set when a bounded spin gives up
+    unsigned long long spin_ticks;  // ... after this many s_memtime ticks without the record it waits for (seconds)
+    int withhold;                // debug (PIPE_HIP_PARAM_DEBUG): tiles with this index publish nothing (-1: none)
     unsigned long long *prof;    // PH_FUSE_PROF builds: [waves][kFuseProfPhases]
 };
 
@@ -182,6 +184,20 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned tag, unsigned v)
 {
     __hip_atomic_store(p, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A spin on a predecessor's record is bounded by TIME (a preempted predecessor may be away for milliseconds; a
+// count of polls says nothing): every 256th poll reads the clock, the first reading starts it.
+__device__ __forceinline__ bool spin_expired(unsigned &spins, unsigned long long &t0, unsigned long long limit)
+{
+    if ((++spins & 255u) != 0u)
+        return false;
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if (t0 == 0ull) {
+        t0 = now;
+        return false;
+    }
+    return now - t0 > limit;
 }
 
 // ---- the cascade's state between launches -------------------------------------------------------
@@ -385,8 +401,9 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
     PH_FSTAMP(2);  // scan
 
     // ---- 4. the tile's true start state ---------------------------------------------------------
+    const bool held = fa.withhold >= 0 && tile == fa.withhold;  // (debug: this tile's records never show up)
     auto publish = [&](int kind, const double (&vr)[N2], const double (&vi)[N2]) {
-        if (l5 == 31 && valid && !last_tile) {
+        if (l5 == 31 && valid && !last_tile && !held) {
             unsigned long long *dst = recs + ((int64_t)tile * 2 + kind) * (2 * NV);
 #pragma unroll
             for (int j = 0; j < N2; ++j) {
@@ -400,7 +417,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         }
     };
     if constexpr (LOCAL) {
-        if (l5 == 31 && valid && !last_tile) {
+        if (l5 == 31 && valid && !last_tile && !held) {
             LocalRec<NV> *r = ring + (gi & (kLocalRing - 1));
 #pragma unroll
             for (int j = 0; j < N2; ++j) {
@@ -455,6 +472,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         }
         bool ready = !(need && u >= 0);
         unsigned spins = 0;
+        unsigned long long spin_t0 = 0;
         if constexpr (LOCAL) {
             const int gp = gi - (l5 + 1) * a.pairs;  // predecessor t - 1 - l5 of this pair
             const LocalRec<NV> *r = ring + (gp & (kLocalRing - 1));
@@ -471,7 +489,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                         ready = true;
                     } else {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 24)) {
+                        if (spin_expired(spins, spin_t0, fa.spin_ticks)) {
                             *fa.err = 1;
                             ready = true;
                         }
@@ -499,7 +517,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                     ready = true;
                 } else {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                    if (spin_expired(spins, spin_t0, fa.spin_ticks)) {  // seconds: something is wrong; give up loudly
                         *fa.err = 1;
                         ready = true;
                     }
@@ -527,6 +545,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
             int dist0 = 0;        // how many predecessors lie between it and the tile (32 per window passed)
             bool done = !valid;
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             while (!__all(done)) {
                 const int u = base - l5;  // the predecessor this lane looks at (-1: the stage's own state)
                 // tags first (the first granule of each record); the payload of the chosen record is
@@ -620,7 +639,7 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
                     }
                 } else if (!done) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {  // seconds: something is wrong; give up loudly
+                    if (spin_expired(spins, spin_t0, fa.spin_ticks)) {  // seconds: something is wrong; give up loudly
                         *fa.err = 1;
                         done = true;
                     }
@@ -838,7 +857,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
 
         // ---- publish this section's aggregate ------------------------------------------------------------
         LocalRec<4> *ring = ring_all + SEC * kLocalRing2;
-        if (l5s == 31 && valid && !last_tile) {
+        if (l5s == 31 && valid && !last_tile && !(fa.withhold >= 0 && tile == fa.withhold)) {
             if constexpr (LOCAL) {
                 LocalRec<4> *r = ring + gi % kLocalRing2;
                 r->v[0] = Zr[0];
@@ -885,6 +904,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
             const bool need = valid && l5s < fc.D && u >= -1;
             bool ready = !(need && u >= 0);
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             if constexpr (LOCAL) {
                 const int gp0 = gi - (l5s + 1) * a.pairs;
                 const int gp = gp0 < 0 ? 0 : gp0;  // (lanes without a predecessor do not look)
@@ -901,7 +921,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
                             ready = true;
                         } else {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1u << 24)) {
+                            if (spin_expired(spins, spin_t0, fa.spin_ticks)) {
                                 *fa.err = 1;
                                 ready = true;
                             }
@@ -929,7 +949,7 @@ __device__ __forceinline__ void fused_epilogue_sections(cd (&lo)[16], cd (&hi)[1
                             ready = true;
                         } else {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1u << 22)) {
+                            if (spin_expired(spins, spin_t0, fa.spin_ticks)) {
                                 *fa.err = 1;
                                 ready = true;
                             }

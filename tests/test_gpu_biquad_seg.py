@@ -355,3 +355,27 @@ def test_one_float32_pipe_buffer_per_call_takes_the_tile_form(sections):
             assert np.array_equal(ex.process(x[k]), w32[k])
             assert np.array_equal(b64.process(x[k].astype(np.float64)), want[k])
         assert not ex.kernel_name().startswith("biquad_tile_kernel") and not b64.kernel_name().startswith("biquad_tile_kernel")
+
+
+def test_a_tile_launch_that_gives_up_is_run_again_through_the_ordered_recurrence():
+    """PIPE_HIP_PARAM_DEBUG on the biquad stage alone: the one-pass tile launch of a synchronous call fails on demand
+    (tile 1 of every series publishes nothing); the carried state goes back to the copy tile 0 made of what it read
+    and the call runs again through the ordered recurrence: bit for bit the oracle's, and the stream goes on."""
+    q = coeffs(1)
+    lines, C, F, B = 8, 2, 16384, 4   # 4 tiles of 4096 frames per Line and call
+    x = np.stack([synth.samples(synth.line_seed(20 + l), 0, B * F * C, np.float32).reshape(B * F, C) for l in range(lines)])
+    want = oracle(q, x)
+    with P.Biquad(q, F, C, dtype=np.float32, lines=lines) as bq:
+        bq.start()
+        for k in range(B):
+            if k == 2:
+                bq._set_param(5, [1.0, 2000.0])  # PIPE_HIP_PARAM_DEBUG {tile, limit_us}
+            got = bq.process(np.ascontiguousarray(x[:, k * F:(k + 1) * F])).reshape(lines, F, C)
+            w = want[:, k * F:(k + 1) * F]
+            if k == 2:
+                assert not bq.kernel_name().startswith("biquad_tile_kernel"), bq.kernel_name()
+                assert np.array_equal(got, w.astype(np.float32))
+            else:
+                assert bq.kernel_name().startswith("biquad_tile_kernel"), bq.kernel_name()
+                err = np.abs(got.astype(np.float64) - w.astype(np.float32).astype(np.float64)) / relaxed_ulp(q, want)[:, k * F:(k + 1) * F]
+                assert err.max() <= 1.0, (k, err.max())

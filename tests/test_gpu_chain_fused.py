@@ -359,3 +359,57 @@ def test_two_sections_with_a_slow_one_take_the_staged_chain(monkeypatch):
     for l in range(lines):
         d = ulps(got[l], oracle_chain(taps, SLOW_PLUS_FAST, None, x[l]))
         assert d.max() <= 1.0, f"line {l}: {d.max()} ulp"
+
+
+def test_a_fused_launch_that_gives_up_is_run_again_staged(monkeypatch):
+    """PIPE_HIP_PARAM_DEBUG: tile 2 of every series publishes nothing and waits give up after 2 ms -- what a preempted
+    predecessor tile does to a launch.  The reference aborts the whole run on a ProcessFunc error (pipe.go:438-440);
+    here a synchronous entry puts the state back (the cascade's from the slot the launch did not write, the FIR's
+    history from the half it did not write), runs the call again on the staged chain and answers OK with the
+    stream's own result; the calls after it are the fused kernel's again and still the stream's."""
+    from pipe_amd import _lib as L
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "64")  # (96 Lines x 6 tiles: fused also on this small call)
+    lines, C, F, N = 96, 2, 4096, 256
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    q = synth.biquad_rbj_lowpass()
+    x = np.stack([synth.samples(synth.line_seed(l), 0, 4 * F * C, np.float32).reshape(4 * F, C) for l in range(lines)])
+    want = np.stack([(O.Biquad(q, C).process(O.Fir(taps, C).process(x[l].astype(np.float64))).reshape(4 * F, C) * 0.5)
+                     for l in range(lines)])
+    kw = dict(dtype=np.float32, lines=lines, max_batch=1)
+    with P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.5, F, C, **kw)]) as ch:
+        ch.start()
+        for k in range(4):
+            if k == 1:
+                ch._set_param(5, [2.0, 2000.0])  # PIPE_HIP_PARAM_DEBUG {tile, limit_us}
+            got = ch.process(np.ascontiguousarray(x[:, k * F:(k + 1) * F]))
+            w = want[:, k * F:(k + 1) * F]
+            floor = 2.0 ** -24 * np.abs(want).max(axis=(1, 2), keepdims=True)
+            ulp = np.spacing(np.maximum(np.abs(w), floor).astype(np.float32)).astype(np.float64)
+            err = np.abs(got.reshape(lines, F, C).astype(np.float64) - w.astype(np.float32).astype(np.float64)) / ulp
+            assert err.max() <= 1.0, (k, err.max())
+            if k != 1:
+                assert ch.kernel_name().startswith("chain_fused_kernel"), (k, ch.kernel_name())
+            else:
+                assert not ch.kernel_name().startswith("chain_fused_kernel"), ch.kernel_name()
+        ch.flush()
+    # asynchronous entry: the failure is reported at the next synchronous one, the state is the one before the batch
+    import torch
+    with P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.5, F, C, **kw)]) as ch:
+        ch.start()
+        d_in = [torch.from_numpy(np.ascontiguousarray(x[:, k * F:(k + 1) * F])).cuda() for k in range(3)]
+        d_out = torch.empty_like(d_in[0])
+        ch.process_batch(d_in[0], d_out, F)
+        ch._set_param(5, [2.0, 2000.0])
+        ch.process_batch(d_in[1], d_out, F)
+        torch.cuda.synchronize()
+        with pytest.raises(L.PipeHipError):
+            ch.flush()
+        for k in (1, 2):  # the failed batch again, then the next one
+            ch.process_batch(d_in[k], d_out, F)
+            torch.cuda.synchronize()
+            w = want[:, k * F:(k + 1) * F]
+            floor = 2.0 ** -24 * np.abs(want).max(axis=(1, 2), keepdims=True)
+            ulp = np.spacing(np.maximum(np.abs(w), floor).astype(np.float32)).astype(np.float64)
+            err = np.abs(d_out.cpu().numpy().reshape(lines, F, C).astype(np.float64) - w.astype(np.float32).astype(np.float64)) / ulp
+            assert err.max() <= 1.0, (k, err.max())
+        ch.flush()
