@@ -261,6 +261,9 @@ const char *pipe_hip_kernel_name(const pipe_hip_processor *p);
 
 /* ---- utilities ------------------------------------------------------------------ */
 int pipe_hip_abi_version(void);
+/* bit 0: the library was built with the A/B-only environment switches (`make AB=1`, libpipe_hip_ab.so); the
+ * default build reads only the knobs DESIGN.md lists */
+int pipe_hip_build_flags(void);
 const char *pipe_hip_strerror(int status);
 int pipe_hip_last_hip_error(void);
 int pipe_hip_device_count(int32_t *count);

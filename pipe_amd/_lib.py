@@ -88,6 +88,7 @@ def lib():
     cfgp = C.POINTER(Config)
     protos = {
         "pipe_hip_abi_version": (C.c_int, []),
+        "pipe_hip_build_flags": (C.c_int, []),
         "pipe_hip_strerror": (C.c_char_p, [C.c_int]),
         "pipe_hip_last_hip_error": (C.c_int, []),
         "pipe_hip_device_count": (C.c_int, [C.POINTER(i32)]),

@@ -255,7 +255,7 @@ struct pipe_hip_processor::Overlap {
 
     static int copy_threads()
     {
-        const char *e = std::getenv("PIPE_HIP_COPY_THREADS");
+        static const char *e = std::getenv("PIPE_HIP_COPY_THREADS");  // (once per process)
         int n = e ? std::atoi(e) : 4;
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && n > hw)
@@ -550,10 +550,25 @@ int pipe_hip_processor::select_device() const
     return PIPE_HIP_OK;
 }
 
+void pipe_hip_processor::Knobs::read()
+{
+    if (const char *e = std::getenv("PIPE_HIP_FIR_OLS_MIN_ITEMS"))
+        fir_ols_min_items = std::atoll(e);
+    if (const char *e = std::getenv("PIPE_HIP_FIR_MFMA_MIN_PASSES"))
+        fir_mfma_min_passes = std::atoll(e);
+    if (const char *e = std::getenv("PIPE_HIP_OVERLAP_MIN_BYTES"))
+        overlap_min_bytes = (size_t)std::atoll(e);
+    if (const char *e = std::getenv("PIPE_HIP_ZERO_COPY_MAX"))
+        zero_copy_max = (size_t)std::atoll(e);
+    if (const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD"))
+        bar_upload = e[0] != '0' ? 1 : 0;
+}
+
 int pipe_hip_processor::init_common(const pipe_hip_config *c)
 {
     PH_TRY(validate_config(c));
     cfg = *c;
+    knobs.read();
     PH_TRY(select_device());
     PH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (Staging &g : stg)
@@ -627,10 +642,7 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     // buffers are therefore processed zero-copy -- the kernels read the pinned staging
     // buffer and write the pinned result buffer straight over PCIe (one launch chain, no
     // hipMemcpyAsync); large ones (many Lines per handle) keep the DMA engines.
-    static const size_t zero_copy_max = [] {
-        const char *e = std::getenv("PIPE_HIP_ZERO_COPY_MAX");
-        return e ? (size_t)std::atoll(e) : (size_t)(1u << 20);
-    }();
+    const size_t zero_copy_max = p->knobs.zero_copy_max;
     const size_t out_b_cap = es * (size_t)p->cfg.lines * (size_t)cap * (size_t)p->out_channels();
     const bool zero_copy = in_b <= zero_copy_max && out_b_cap <= zero_copy_max && g.hd_in && g.hd_out;
     if (in_b)
@@ -699,13 +711,6 @@ struct WindowGuard {  // whatever happens, the handle goes back to "all Lines"
     ~WindowGuard() { p->set_window(0, 0); }
 };
 
-// Calls at least this large (input bytes) with two or more Lines are cut into chunks of Lines.
-size_t overlap_min_bytes()
-{
-    const char *e = std::getenv("PIPE_HIP_OVERLAP_MIN_BYTES");  // (read per call: tests switch it)
-    return e ? (size_t)std::atoll(e) : (size_t)4 << 20;
-}
-
 // Lines [first, first + count) of a fixed-rate handle, every one `frames` frames: in_of(l) /
 // out_of(l) are the HOST rows of Line l; the chunk rows sit packed in the handle's staging buffers
 // from byte in_off0 / out_off0.  Synchronous: on return the outputs are in the caller's buffers.
@@ -755,10 +760,9 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
     // of a copy into pinned memory plus a DMA.  PIPE_HIP_BAR_UPLOAD=0 keeps the DMA path.
     {
         const BarInfo bi = bar_info(p->cfg.device);
-        const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD");
         // default: where the device has a large BAR AND says where its HDP flush register is; without the
         // register only on request (PIPE_HIP_BAR_UPLOAD=1: a platform whose host writes are coherent without it)
-        c.bar = bi.large_bar && (e ? e[0] != '0' : bi.hdp_flush != nullptr);
+        c.bar = bi.large_bar && (p->knobs.bar_upload >= 0 ? p->knobs.bar_upload != 0 : bi.hdp_flush != nullptr);
         c.hdp_flush = bi.hdp_flush;
         if (c.bar) {
             // ... and the staging buffer really is writable in this process's address space (asked once per
@@ -771,7 +775,7 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
             c.bar = ov.bar_ok;
         }
     }
-    c.trace = std::getenv("PIPE_HIP_OVERLAP_TRACE") != nullptr;  // debug: where a call's time goes
+    c.trace = PH_ENV_AB("PIPE_HIP_OVERLAP_TRACE") != nullptr;  // debug: where a call's time goes
     c.t0 = std::chrono::steady_clock::now();
     c.tr.assign(c.trace ? nchunks * 5 : 0, 0.0);
     WindowGuard guard{p};
@@ -799,6 +803,15 @@ int process_overlapped(pipe_hip_processor *p, int first, int count, int32_t fram
 extern "C" {
 
 int pipe_hip_abi_version(void) { return PIPE_HIP_ABI_VERSION; }
+
+int pipe_hip_build_flags(void)
+{
+#ifdef PIPE_HIP_AB
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char *pipe_hip_strerror(int status)
 {
@@ -966,7 +979,7 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         const size_t es = dtype_size(p->cfg.dtype);
         const size_t row_in = es * (size_t)in_frames * (size_t)p->cfg.channels;
         const size_t row_out = es * (size_t)in_frames * (size_t)p->out_channels();
-        if (row_in * (size_t)p->cfg.lines >= overlap_min_bytes()) {
+        if (row_in * (size_t)p->cfg.lines >= p->knobs.overlap_min_bytes) {  // (calls this large: chunks of Lines)
             PH_TRY(p->enter());
             PH_TRY(p->ensure_staging());
             const char *ib = static_cast<const char *>(in);
@@ -1094,7 +1107,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
     const size_t es = dtype_size(p->cfg.dtype);
     // the usual pass -- one run, many Lines, tens of MB: chunks of Lines, transfers and kernels overlapped
     if (runs.size() == 1 && runs[0].count >= 2 &&
-        es * (size_t)runs[0].frames * (size_t)p->cfg.channels * (size_t)runs[0].count >= overlap_min_bytes()) {
+        es * (size_t)runs[0].frames * (size_t)p->cfg.channels * (size_t)runs[0].count >= p->knobs.overlap_min_bytes) {
         const LineRun &r = runs[0];
         PH_TRY(process_overlapped(
             p, r.first, r.count, r.frames,

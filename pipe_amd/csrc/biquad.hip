@@ -1425,7 +1425,7 @@ public:
         if (segmented) {
             // few series: lanes are (segment, series) pairs, more and shorter segments (the serial scan over them
             // bounds their number)
-            a.spb = a.nseries < kThreads && !std::getenv("PIPE_HIP_BIQUAD_SEG_ONE_PER_BLOCK") ? kThreads / a.nseries : 0;
+            a.spb = a.nseries < kThreads && !PH_ENV_AB("PIPE_HIP_BIQUAD_SEG_ONE_PER_BLOCK") ? kThreads / a.nseries : 0;
             const int tmax = a.spb > 0 ? 4096 : 1024;
             int T = (int)(frames / 64);
             T = T < 2 ? 2 : (T > tmax ? tmax : T);
@@ -1446,7 +1446,7 @@ public:
         // set in the environment is the only rule when it is there.
         const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && a.nseries <= kTileLatencySeries;
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
-                           frames >= tile_min_frames_ && !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") &&
+                           frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") &&
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
         // 3 or 4 sections: the tile kernel holds two, so two tile passes over the halves of the cascade with a float64
         // stream between them (24 bytes a sample instead of 8) -- where the lane walk crawls (few Lines or channels)
@@ -1460,9 +1460,9 @@ public:
             // segments of 32 frames, or of 16 where that fills the tiles better by a quarter of the call
             const int64_t t32 = tspc * 32, t16 = tspc * 16;
             const int64_t waste32 = (frames + t32 - 1) / t32 * t32 - frames, waste16 = (frames + t16 - 1) / t16 * t16 - frames;
-            const char *seg_env = std::getenv("PIPE_HIP_BIQUAD_TILE_SEG");  // A/B: 16 or 32 whatever the shape
+            const char *seg_env = PH_ENV_AB("PIPE_HIP_BIQUAD_TILE_SEG");  // A/B: 16 or 32 whatever the shape
             const int seg = seg_env ? (std::atoi(seg_env) == 16 ? 16 : 32)
-                                    : (waste32 - waste16 > frames / 4 && !std::getenv("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32);
+                                    : (waste32 - waste16 > frames / 4 && !PH_ENV_AB("PIPE_HIP_BIQUAD_TILE_SEG32") ? 16 : 32);
             const int tfr = (int)(seg == 32 ? t32 : t16);
             a.T = (int)((frames + tfr - 1) / tfr);
             a.seglen = tfr;
@@ -1491,7 +1491,7 @@ public:
             const dim3 tgrid((unsigned)a.T * (unsigned)nl);
             const size_t lds_rest = sizeof(double) * ((size_t)kTileThreads * 2u * (size_t)S_ + 8u * 2u * (size_t)S_);
             const int cmagic = (65536 + tc - 1) / tc;
-            const bool single = !std::getenv("PIPE_HIP_BIQUAD_TWO_PASS");
+            const bool single = !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS");
             BiquadLookArgs lk{};
             if (ext_state_ && !single)
                 return PIPE_HIP_EINVAL;
@@ -1522,7 +1522,7 @@ public:
                                    (int)lds));                                                                        \
         hipLaunchKernelGGL(k1, tgrid, dim3(kTileThreads), lds, s, static_cast<const TI *>(d_in),                      \
                            static_cast<TO *>(d_out), a, q_, pw_, a.T, tc, tspc, cmagic, lk, mfull_);                  \
-        if (a.T > kWaveScanMinTiles && !std::getenv("PIPE_HIP_BIQUAD_NO_WAVE_SCAN"))                                \
+        if (a.T > kWaveScanMinTiles && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_WAVE_SCAN"))                                \
             launch_scan_wave(s, a);                                                                                   \
         else                                                                                                          \
             launch_scan(sblocks, s, a, mlast_);                                                                       \
@@ -1821,7 +1821,7 @@ public:
     // ProcessFunc form); with thousands of series the register form's 64 busy lanes per wave do.
     static bool no_sp()  // A/B knob
     {
-        static const bool v = std::getenv("PIPE_HIP_BIQUAD_NO_SP") != nullptr;
+        static const bool v = PH_ENV_AB("PIPE_HIP_BIQUAD_NO_SP") != nullptr;
         return v;
     }
     // The section-pipelined form: always where the LDS-staged form applies; with three or more
@@ -1834,7 +1834,7 @@ public:
             return false;
         if (use_lds_form())
             return true;
-        static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");
+        static const char *env = PH_ENV_AB("PIPE_HIP_BIQUAD_LDS");
         if (env)
             return false;
         const int64_t wgs = (int64_t)active_lines() * ((cfg.channels + kSpChannels - 1) / kSpChannels);
@@ -1854,7 +1854,7 @@ public:
     mutable int cus_ = 0;
     bool use_lds_form() const
     {
-        static const char *env = std::getenv("PIPE_HIP_BIQUAD_LDS");
+        static const char *env = PH_ENV_AB("PIPE_HIP_BIQUAD_LDS");
         if (env)
             return std::atoi(env) != 0;
         return active_lines() * ((cfg.channels + 63) / 64) <= 256 && active_lines() * cfg.channels <= 2048;
@@ -1875,9 +1875,9 @@ public:
     // the next call, whatever form it takes) finds the state where it always is
     bool split_wanted(int nl) const
     {
-        if (std::getenv("PIPE_HIP_BIQUAD_NO_SPLIT"))
+        if (PH_ENV_AB("PIPE_HIP_BIQUAD_NO_SPLIT"))
             return false;
-        const char *e = std::getenv("PIPE_HIP_BIQUAD_SPLIT_MAX_SERIES");
+        const char *e = PH_ENV_AB("PIPE_HIP_BIQUAD_SPLIT_MAX_SERIES");
         // (one channel: the lane walk drags a cache line per lane whatever the number of Lines -- 4096 x 1 ch, 3 sections: 68)
         return (int64_t)nl * cfg.channels <= (e ? std::atoll(e) : kSplitMaxSeries) || (cfg.channels == 1 && !e);
     }
@@ -1902,8 +1902,8 @@ public:
         double *stb = static_cast<double *>(half_[1]->state_.p) + (size_t)win_first * cfg.channels * 2u * sb;
         // the one-pass tile kernel reads and writes a series' state at any stride: the halves then work on this
         // handle's array itself; any other form of a half (an A/B switch, a half that must stay exact) works on a copy
-        const bool direct = !std::getenv("PIPE_HIP_BIQUAD_NO_TILE") && !std::getenv("PIPE_HIP_BIQUAD_TWO_PASS") &&
-                            !std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES") && !std::getenv("PIPE_HIP_BIQUAD_SPLIT_COPIES") &&
+        const bool direct = !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") && !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS") &&
+                            !PH_ENV_AB("PIPE_HIP_BIQUAD_TILE_WALK_LINES") && !PH_ENV_AB("PIPE_HIP_BIQUAD_SPLIT_COPIES") &&
                             half_[0]->relaxed_ok() && half_[1]->relaxed_ok();
         for (int h = 0; h < 2; ++h) {
             half_[h]->ext_state_ = direct ? static_cast<double *>(state_.p) : nullptr;
@@ -2112,7 +2112,12 @@ private:
     const int64_t tile_min_frames_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES"))
                                          : 512;  // (shorter Lines leave the tiles mostly empty: 16384 x 1 ch x 128 frames 38 Gsamples/s against the lane walk's 87; at 256 frames even, at 512 150 against 88)
-    const int tile_walk_lines_ = std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES") ? std::atoi(std::getenv("PIPE_HIP_BIQUAD_TILE_WALK_LINES")) : kTileWalkLines;
+    static int walk_lines_knob()
+    {
+        const char *e = PH_ENV_AB("PIPE_HIP_BIQUAD_TILE_WALK_LINES");
+        return e ? std::atoi(e) : kTileWalkLines;
+    }
+    const int tile_walk_lines_ = walk_lines_knob();
     BiquadTransition mfull_{}, mlast_{};
     int mfull_len_ = -1, mlast_len_ = -1;  // (the lane-walk form computes its own last-segment matrix per call)
     BiquadTilePowers pw_{};

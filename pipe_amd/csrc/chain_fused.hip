@@ -364,7 +364,7 @@ bool Plan::accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipSt
     if (S == 1)
         return true;
     (void)frames;
-    if (S != 2 || std::getenv("PIPE_HIP_CHAIN_GENERAL") || std::getenv("PIPE_HIP_CHAIN_ONE_SECTION"))
+    if (S != 2 || PH_ENV_AB("PIPE_HIP_CHAIN_GENERAL") || PH_ENV_AB("PIPE_HIP_CHAIN_ONE_SECTION"))
         return false;
     if (prepare(coeffs, S, ntaps, s) != PIPE_HIP_OK)
         return false;
@@ -680,7 +680,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     I.last_stream = s;
     // a filter that forgets within one look-back window (D <= 32) takes the kernel without P
     // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
-    static const bool force_general = std::getenv("PIPE_HIP_CHAIN_GENERAL") != nullptr;
+    static const bool force_general = PH_ENV_AB("PIPE_HIP_CHAIN_GENERAL") != nullptr;
     const bool general = force_general || I.D > 32;
     if (S < 1 || S > kMaxFusedSections || (S == 2 && general))
         return PIPE_HIP_EINVAL;  // (Plan::accepts said otherwise: the caller did not ask)
@@ -688,13 +688,13 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // Block-local look-back (ols32_kernel.hpp): at least as many Lines as CUs -- a workgroup per CU,
     // whole Lines per workgroup, balanced to within one Line -- and predecessors within the record
     // ring's reach.  PIPE_HIP_CHAIN_LOCAL=0 switches it off (tests, A/B).
-    const char *local_env = std::getenv("PIPE_HIP_CHAIN_LOCAL");
+    const char *local_env = PH_ENV_AB("PIPE_HIP_CHAIN_LOCAL");
     const bool local = !general && !(local_env && local_env[0] == '0') && lines >= P.cus &&
                        (int64_t)I.D * a.pairs <= (S == 2 ? ols::kLocalReach2 : ols::kLocalReach) &&
                        (lines % P.cus == 0 || lines >= 8 * P.cus);
     a.local = local ? 1 : 0;
     {
-        const char *e = std::getenv("PIPE_HIP_CHAIN_STAGGER");  // A/B knob
+        const char *e = PH_ENV_AB("PIPE_HIP_CHAIN_STAGGER");  // A/B knob
         a.stagger = e ? std::atoi(e) : 0;
     }
     if (S == 2) {
@@ -723,7 +723,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     }
     // the state after every Line's last frame: the fused kernel's own work when the Line ends on a
     // segment boundary (PIPE_HIP_CHAIN_NO_TAIL: debug switch)
-    if (frames % 32 != 0 && !std::getenv("PIPE_HIP_CHAIN_NO_TAIL")) {
+    if (frames % 32 != 0 && !PH_ENV_AB("PIPE_HIP_CHAIN_NO_TAIL")) {
         TailArgs ta{};
         ta.frames = frames;
         ta.line_stride = a.line_stride;

@@ -160,10 +160,32 @@ private:
 
 }  // namespace pipehip
 
+// ---- environment switches ------------------------------------------------------------------------------
+// The shipped library reads a dozen tuning knobs, once per handle (pipe_hip_processor::Knobs) or once per
+// process -- DESIGN.md lists them.  The switches that exist only to A/B kernel variants against each other
+// (thresholds under study, alternative forms, traces) are compiled in by `make AB=1` (-DPIPE_HIP_AB,
+// lib/libpipe_hip_ab.so) and do not exist in the default build: PH_ENV_AB() is then a null pointer and the
+// variable's name is not even in the binary.
+#ifdef PIPE_HIP_AB
+#define PH_ENV_AB(name) std::getenv(name)
+#else
+#define PH_ENV_AB(name) (static_cast<const char *>(nullptr))
+#endif
+
 // The opaque handle of the C ABI.  One object == one Processor component of a
 // Line (pipe.go:49-60) -- or of `lines` identical Lines batched together.
 struct pipe_hip_processor {
     pipe_hip_config cfg{};
+    // the shipped tuning knobs, read from the environment when the handle is made (init_common)
+    struct Knobs {
+        int64_t fir_ols_min_items = -1;     // PIPE_HIP_FIR_OLS_MIN_ITEMS: smallest call (1024-point transforms) for the overlap-save FIR (default 8 per CU)
+        int64_t fir_mfma_min_passes = 32;   // PIPE_HIP_FIR_MFMA_MIN_PASSES: smallest call (passes of 1024 frames x 2 ch) for the matrix-pipe FIR
+        size_t overlap_min_bytes = (size_t)4 << 20;  // PIPE_HIP_OVERLAP_MIN_BYTES: smallest host call cut into overlapped chunks of Lines
+        size_t zero_copy_max = (size_t)1 << 20;      // PIPE_HIP_ZERO_COPY_MAX: largest buffer the kernels read / write in pinned host memory
+        int bar_upload = -1;                // PIPE_HIP_BAR_UPLOAD: 0 never, 1 also without an HDP flush register, unset: where the device has one
+        void read();
+    };
+    Knobs knobs;
     hipStream_t stream = nullptr;  // the handle's own stream
     hipStream_t batch_stream = nullptr;  // a caller's stream the last device-resident call went to (if not `stream`)
     // StartFunc / FlushFunc order themselves after everything the handle has queued anywhere

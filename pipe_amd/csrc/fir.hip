@@ -589,7 +589,7 @@ public:
         const double *taps = static_cast<const double *>(taps_[cur_taps_].p);
         // the ordered-fma form: large calls on the float64 matrix pipe (fir_mfma.hip: the same chain
         // of fused multiply-adds, 1024 of them per instruction), the rest on the VALU
-        if (fir_mfma_takes(N_, frames, cfg.channels, nl, cus_)) {
+        if (fir_mfma_takes(N_, frames, cfg.channels, nl, cus_, knobs.fir_mfma_min_passes)) {
             hipEvent_t *done = windowed() ? nullptr : &completion;
             PH_TRY(run_fir_mfma(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, taps, N_, frames, cfg.channels, nl,
                                 cus_, s, &last_kernel, &timer, done));
@@ -660,9 +660,7 @@ private:
     // enough 1024-point transforms to give every SIMD of the chip a few
     int64_t ols_min_items() const
     {
-        if (const char *f = std::getenv("PIPE_HIP_FIR_OLS_MIN_ITEMS"))
-            return std::atoll(f);
-        return 8 * (int64_t)cus_;
+        return knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 8 * (int64_t)cus_;
     }
 
     // the history of all Lines into the other half of the double buffer in the other element type
@@ -743,7 +741,7 @@ private:
         static const int Rs[] = {16, 8, 4, 2, 1};
         bool have = false;
         // tuning knob for experiments: PIPE_HIP_FIR_R pins the register blocking
-        const char *force = std::getenv("PIPE_HIP_FIR_R");
+        const char *force = PH_ENV_AB("PIPE_HIP_FIR_R");
         const int forced = force ? std::atoi(force) : 0;
         const int64_t want = 2 * (int64_t)cus_;
         for (int R : Rs) {
@@ -774,7 +772,7 @@ private:
                 ok = geometry(4, ++split, frames, &g);
             if (ok) {
                 *best = g;
-                static const bool no_lt = std::getenv("PIPE_HIP_FIR_NO_LT") != nullptr;  // A/B knob
+                static const bool no_lt = PH_ENV_AB("PIPE_HIP_FIR_NO_LT") != nullptr;  // A/B knob
                 best->lt = !kLdsTaps && !no_lt;
             }
         }
@@ -829,7 +827,7 @@ private:
             (void)hipGetLastError();
             per_cu = 2;
         }
-        if (const char *f = std::getenv("PIPE_HIP_FIR_WGS_PER_CU"))  // tuning knob
+        if (const char *f = PH_ENV_AB("PIPE_HIP_FIR_WGS_PER_CU"))  // tuning knob
             per_cu = std::atoi(f) > 0 ? std::atoi(f) : per_cu;
         const int64_t slots = (int64_t)per_cu * cus_;
         const int64_t per = (g.ntiles + slots - 1) / slots;

@@ -267,9 +267,9 @@ fir_mfma_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base, co
 
 }  // namespace
 
-bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus)
+bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus, int64_t min_passes)
 {
-    if (std::getenv("PIPE_HIP_FIR_NO_MFMA"))
+    if (PH_ENV_AB("PIPE_HIP_FIR_NO_MFMA"))
         return false;
     if (ntaps < 16 || ntaps > kFirMfmaMaxTaps || frames <= 0)
         return false;
@@ -279,8 +279,7 @@ bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus)
     (void)cus;
     const int64_t groups = (channels + 1) / 2;
     const int64_t passes = ((frames + 1023) / 1024) * lines * groups;
-    const char *force = std::getenv("PIPE_HIP_FIR_MFMA_MIN_PASSES");  // (tests: 1 sends small calls here too)
-    return passes >= (force ? std::atoll(force) : 32);
+    return passes >= min_passes;  // (the handle's PIPE_HIP_FIR_MFMA_MIN_PASSES, default 32; tests: 1 sends small calls here too)
 }
 
 int run_fir_mfma(const void *d_in, int in_dtype, void *d_out, int out_dtype, const double *hist, double *hist_new,
@@ -303,7 +302,7 @@ int run_fir_mfma(const void *d_in, int in_dtype, void *d_out, int out_dtype, con
     a.TF = 2048;
     if (((frames + 2047) / 2048) * lines * a.ngroups < 2 * (int64_t)cus)
         a.TF = 1024;
-    if (const char *e = std::getenv("PIPE_HIP_FIR_MFMA_TF"))  // A/B: 1024 / 2048 / 4096
+    if (const char *e = PH_ENV_AB("PIPE_HIP_FIR_MFMA_TF"))  // A/B: 1024 / 2048 / 4096
         if (std::atoi(e) >= 256 && std::atoi(e) % 256 == 0)
             a.TF = std::atoi(e);
     a.tiles_per_line = (int)((frames + a.TF - 1) / a.TF);

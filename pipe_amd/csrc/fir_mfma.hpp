@@ -11,7 +11,7 @@ class KernelTimer;
 constexpr int kFirMfmaMaxTaps = 4096;
 
 // whether a call of this size goes to the matrix-pipe kernel (else fir.hip's VALU kernels)
-bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus);
+bool fir_mfma_takes(int ntaps, int64_t frames, int channels, int lines, int cus, int64_t min_passes);
 
 // one launch: `lines` Lines of `frames` frames x `channels` interleaved, history [lines][ntaps - 1][channels]
 // float64 in `hist`, the next call's in `hist_new`.  *completion (may be null): handed to the launch as its

@@ -421,7 +421,7 @@ bool Plan::supports(int ntaps, int channels)
     if (std::getenv("PIPE_HIP_FIR_EXACT"))
         return false;
     // up to 512 taps: one spectrum; 513 .. 4096: partitioned (even channel counts: the 32 x 32 kernel)
-    return ntaps >= 16 && (ntaps <= 512 || (ntaps <= 4096 && (channels % 2 == 0 || channels == 1) && !std::getenv("PIPE_HIP_FIR_NO_PARTITION")));
+    return ntaps >= 16 && (ntaps <= 512 || (ntaps <= 4096 && (channels % 2 == 0 || channels == 1) && !PH_ENV_AB("PIPE_HIP_FIR_NO_PARTITION")));
 }
 
 // H[k] = (1/M) sum_n h[n] exp(-2 pi i n k / M) for k = 0..M/2 (the kernels take the upper half from
@@ -504,7 +504,7 @@ int Plan::init(int device, const double *taps, int ntaps)
         // partitions of exactly 512 taps (the last one zero-padded): the hop of the frequency-domain
         // delay line; PIPE_HIP_FIR_PARTITION_SUM cuts them evenly for the sum-of-partitions kernel (A/B)
         impl_->P = (ntaps + 511) / 512;
-        impl_->Np = std::getenv("PIPE_HIP_FIR_PARTITION_SUM") ? (ntaps + impl_->P - 1) / impl_->P : 512;
+        impl_->Np = PH_ENV_AB("PIPE_HIP_FIR_PARTITION_SUM") ? (ntaps + impl_->P - 1) / impl_->P : 512;
         const size_t pb = sizeof(double) * 2 * (kHalf + 1) * (size_t)impl_->P;
         PH_TRY(impl_->hpart[0].alloc(pb));
         PH_TRY(impl_->hpart[1].alloc(pb));
@@ -616,7 +616,7 @@ int Plan::run(const void *d_in, int in_dtype, void *d_out, int out_dtype, const 
     const bool vec16 = channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
     // the 32 x 32 decomposition (one transform per half-wave, fir_ols32.hip): even channel counts
     // (default; PIPE_HIP_OLS_VARIANT=16 selects the 16 x 16 x 4 kernel of this file for A/B runs)
-    static const int variant = std::getenv("PIPE_HIP_OLS_VARIANT") ? std::atoi(std::getenv("PIPE_HIP_OLS_VARIANT")) : 32;
+    static const int variant = PH_ENV_AB("PIPE_HIP_OLS_VARIANT") ? std::atoi(PH_ENV_AB("PIPE_HIP_OLS_VARIANT")) : 32;
     if (vec && variant == 32)
         return run_ols32(*impl_, d_in, in_dtype, d_out, out_dtype, hist, hist_new, frames, channels, lines, s,
                          kernel_name, timer);

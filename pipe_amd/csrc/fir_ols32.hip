@@ -92,7 +92,7 @@ int run_ols32(const Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, 
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
     // one channel: two tiles of the Line per complex sequence (tile t and tile t + half the tiles) -- the same
     // efficiency as a channel pair; a Line of one tile, or PIPE_HIP_OLS_MONO_ALONE (A/B), keeps the channel alone
-    const bool mono = channels == 1 && a.tiles_per_line >= 2 && !std::getenv("PIPE_HIP_OLS_MONO_ALONE");
+    const bool mono = channels == 1 && a.tiles_per_line >= 2 && !PH_ENV_AB("PIPE_HIP_OLS_MONO_ALONE");
     if (mono) {
         a.tiles_per_line = (a.tiles_per_line + 1) / 2;
         a.mono_shift = (int64_t)a.tiles_per_line * a.L;

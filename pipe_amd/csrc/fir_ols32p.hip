@@ -649,7 +649,7 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
 {
     // the frequency-domain delay line (two transforms per tile): the plan's spectra are cut every 512
     // taps for it (Plan::init); PIPE_HIP_FIR_PARTITION_SUM selects the sum-of-partitions kernel (A/B)
-    if (I.Np == 512 && !std::getenv("PIPE_HIP_FIR_PARTITION_SUM")) {
+    if (I.Np == 512 && !PH_ENV_AB("PIPE_HIP_FIR_PARTITION_SUM")) {
         ArgsD d{};
         Args32 &a = d.a;
         a.frames = frames;
@@ -678,7 +678,7 @@ int run_ols32p(Plan::Impl &I, const void *d_in, int in_dtype, void *d_out, int o
         // of them finish sooner (512 Lines of 8 tiles, 1024 taps: runs of 2 tiles on 1024 waves against
         // runs of 8 on 256).  PIPE_HIP_FIR_RUN_FLOOR=n restores a floor of n P tiles (A/B).
         int64_t R = ((int64_t)a.tiles_per_line * series + 2 * waves - 1) / (2 * waves);
-        const char *rf = std::getenv("PIPE_HIP_FIR_RUN_FLOOR");
+        const char *rf = PH_ENV_AB("PIPE_HIP_FIR_RUN_FLOOR");
         const int run_floor = rf && std::atoi(rf) > 0 ? std::atoi(rf) : 1;
         if (R < run_floor * (int64_t)d.P)
             R = run_floor * (int64_t)d.P;

@@ -784,7 +784,7 @@ public:
         // taps in registers: T one of the specialised sizes and `up` small enough that a
         // workgroup's lanes cover whole periods of the phase pattern
         const bool reg_taps = (T_ == 8 || T_ == 12 || T_ == 16 || T_ == 24 || T_ == 32) && up_ <= kThreads &&
-                              !std::getenv("PIPE_HIP_RESAMPLE_LDS_TAPS");
+                              !PH_ENV_AB("PIPE_HIP_RESAMPLE_LDS_TAPS");
         const int q = reg_taps ? up_ * (kThreads / up_) : kThreads;
         // (taps in registers: as many waves as hold the q computing lanes, e.g. 3 for 160)
         const int threads = reg_taps ? (q + 63) / 64 * 64 : kThreads;
@@ -794,7 +794,7 @@ public:
         // float32 streams with the taps in registers keep the window as float32 channel pairs
         // (from four channels on: with two the float64 planes are faster, 51.5 against 59.7 us)
         const bool f32win = reg_taps && in_dtype == PIPE_HIP_F32 && cfg.channels % 2 == 0 && cfg.channels >= 4 && T_ % 4 == 0 &&
-                            !std::getenv("PIPE_HIP_RESAMPLE_F64_PLANES");
+                            !PH_ENV_AB("PIPE_HIP_RESAMPLE_F64_PLANES");
         int tile_out = 0, win = 0, plane = 0;
         size_t lds = 0;
         for (int cap = kOutTile; cap >= q; cap /= 2) {
@@ -827,7 +827,7 @@ public:
         if (total > 0 && n_out > 0 && launch_pair(a, in_dtype, out_dtype, reg_taps, s))
             return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         const bool big_lds = lds > 64 * 1024;
-        const bool tiled = lds <= (reg_taps ? (size_t)64 * 1024 : kBigLds) && n_out > 0 && !std::getenv("PIPE_HIP_RESAMPLE_GATHER");
+        const bool tiled = lds <= (reg_taps ? (size_t)64 * 1024 : kBigLds) && n_out > 0 && !PH_ENV_AB("PIPE_HIP_RESAMPLE_GATHER");
         if (total > 0 && tiled) {
             TiledArgs t{};
             t.r = a;
@@ -975,7 +975,7 @@ private:
     // true when the pair kernel took the call
     bool launch_pair(const ResampleArgs &a, int in_dtype, int out_dtype, bool reg_taps, hipStream_t s)
     {
-        if (cfg.channels != 2 || !reg_taps || T_ % 4 != 0 || std::getenv("PIPE_HIP_RESAMPLE_NO_PAIR"))
+        if (cfg.channels != 2 || !reg_taps || T_ % 4 != 0 || PH_ENV_AB("PIPE_HIP_RESAMPLE_NO_PAIR"))
             return false;
         const int dmin = down_ / up_;
         if (dmin > 1)
