@@ -1193,6 +1193,81 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
         wout[l] = live ? (int)((size_t)in_frames[l] * fb_out / 8) : 0;
     }
     WindowGuard guard{p};
+    // The usual pass -- one run, many Lines, tens of MB: chunks of Lines on three streams, the row kernels of chunk
+    // k + 1 reading the caller's pinned buffers over PCIe while chunk k's stage kernels run and chunk k - 1's rows
+    // go back (PCIe is full duplex: the call costs the longer direction, not the sum).  Everything is queued up
+    // front; no host thread copies anything.
+    if (runs.size() == 1 && runs[0].count >= 2 &&
+        fb_in * (size_t)runs[0].frames * (size_t)runs[0].count >= p->knobs.overlap_min_bytes) {
+        const LineRun &r = runs[0];
+        if (!p->overlap) {
+            p->overlap = new pipe_hip_processor::Overlap();
+            p->overlap->device = p->cfg.device;
+        }
+        pipe_hip_processor::Overlap &ov = *p->overlap;
+        if (!ov.s_in) {
+            PH_HIP(hipStreamCreateWithFlags(&ov.s_in, hipStreamNonBlocking));
+            PH_HIP(hipStreamCreateWithFlags(&ov.s_out, hipStreamNonBlocking));
+        }
+        const size_t row_in = fb_in * (size_t)r.frames, row_out = fb_out * (size_t)r.frames;
+        const char *cmb = PH_ENV_AB("PIPE_HIP_PINNED_CHUNK_MB");  // A/B: chunk size
+        size_t nchunks = row_in * (size_t)r.count / ((size_t)(cmb ? std::atoi(cmb) : 8) << 20);
+        nchunks = nchunks < 4 ? 4 : (nchunks > 64 ? 64 : nchunks);
+        if (nchunks > (size_t)r.count)
+            nchunks = (size_t)r.count;
+        const int per = (int)((r.count + nchunks - 1) / nchunks);
+        nchunks = (size_t)((r.count + per - 1) / per);
+        PH_TRY(ov.events(3 * nchunks));
+        // Rows that lie back to back in ONE pinned block (a pool carved from one pipe_hip_host_alloc) move by the
+        // DMA engines, a chunk per copy: both directions at once reach 48 GB/s each way on this link
+        // (scripts/micro/pcie_rates.hip), where a reading and a writing kernel side by side share 56 -- they
+        // take turns.  Scattered rows keep the row kernels.
+        bool dense = true;
+        for (int i = 0; i < r.count && dense; ++i) {
+            const int l = r.first + i;
+            dense = tin[l] && tout[l] && win[l] == (int)(row_in / 8) &&
+                    static_cast<const char *>(tin[l]) == static_cast<const char *>(tin[r.first]) + row_in * (size_t)i &&
+                    static_cast<char *>(tout[l]) == static_cast<char *>(tout[r.first]) + row_out * (size_t)i;
+        }
+        // (s_in / s_out start behind whatever the handle's stream has queued: state and parameter uploads)
+        PH_HIP(hipEventRecord(ov.ev[0], p->stream));
+        PH_HIP(hipStreamWaitEvent(ov.s_in, ov.ev[0], 0));
+        int rc = PIPE_HIP_OK;
+        for (size_t k = 0; k < nchunks && rc == PIPE_HIP_OK; ++k) {
+            const int l0 = (int)k * per, n = l0 + per <= r.count ? per : r.count - l0;
+            char *din = static_cast<char *>(p->stg[0].d_in.p) + r.in_off + row_in * (size_t)l0;
+            char *dout = static_cast<char *>(p->stg[0].d_out.p) + r.out_off + row_out * (size_t)l0;
+            hipEvent_t up = ov.ev[3 * k + 1], done = ov.ev[3 * k + 2];
+            if (dense)
+                PH_HIP(hipMemcpyAsync(din, static_cast<const char *>(tin[r.first]) + row_in * (size_t)l0, row_in * (size_t)n,
+                                      hipMemcpyHostToDevice, ov.s_in));
+            else
+                rc = launch_gather_rows(tin + r.first + l0, win + r.first + l0, din, (int)(row_in / 8), n, ov.s_in);
+            if (rc != PIPE_HIP_OK)
+                break;
+            PH_HIP(hipEventRecord(up, ov.s_in));
+            PH_HIP(hipStreamWaitEvent(p->stream, up, 0));
+            p->set_window(r.first + l0, (r.first + l0 == 0 && n == L) ? 0 : n);
+            int64_t produced = r.frames;
+            rc = p->run_var(din, p->cfg.dtype, r.frames, dout, p->cfg.dtype, r.frames, &produced, p->stream);
+            if (rc != PIPE_HIP_OK)
+                break;
+            PH_HIP(hipEventRecord(done, p->stream));
+            PH_HIP(hipStreamWaitEvent(ov.s_out, done, 0));
+            if (dense)
+                PH_HIP(hipMemcpyAsync(static_cast<char *>(tout[r.first]) + row_out * (size_t)l0, dout, row_out * (size_t)n,
+                                      hipMemcpyDeviceToHost, ov.s_out));
+            else
+                rc = launch_scatter_rows(tout + r.first + l0, wout + r.first + l0, dout, (int)(row_out / 8), n, ov.s_out);
+        }
+        // (on an error too: nothing of this call may still be running when its tables go away)
+        const hipError_t e0 = hipStreamSynchronize(ov.s_in), e1 = hipStreamSynchronize(p->stream), e2 = hipStreamSynchronize(ov.s_out);
+        PH_TRY(rc);
+        PH_HIP(e0);
+        PH_HIP(e1);
+        PH_HIP(e2);
+        return p->poll_error();
+    }
     for (const LineRun &r : runs) {
         int64_t produced = r.frames;
         char *din = static_cast<char *>(p->stg[0].d_in.p) + r.in_off;

@@ -171,6 +171,29 @@ class Processor:
             raise ValueError("need one entry per Line")
         out_ch, _, _ = self.output_properties()
         keep, ins, outs, frames = [], [], [], []
+        slabs = []
+        if pinned == "slab":
+            # every row carved from ONE pinned block per direction, back to back in Line order (a pool built on
+            # pipe_hip_host_alloc): rows of equal length then move by the DMA engines, a chunk of Lines per copy
+            rows = [None if x is None else np.ascontiguousarray(x, dtype=self.dtype).reshape(-1, self.channels) for x in xs]
+            nin = sum(r.size for r in rows if r is not None)
+            nout = sum(r.shape[0] * out_ch for r in rows if r is not None)
+            bi = self._pinned_like(np.empty(max(nin, 1), dtype=self.dtype))
+            bo = self._pinned_like(np.empty(max(nout, 1), dtype=self.dtype))
+            slabs = [bi, bo]
+            pi = po = 0
+            for r in rows:
+                if r is None:
+                    ins.append(None); outs.append(None); frames.append(0); keep.append(None)
+                    continue
+                a = bi[pi:pi + r.size].reshape(r.shape)
+                a[...] = r
+                o = bo[po:po + r.shape[0] * out_ch].reshape(r.shape[0], out_ch)
+                pi += r.size
+                po += r.shape[0] * out_ch
+                keep.append((a, o))
+                ins.append(a.ctypes.data); outs.append(o.ctypes.data); frames.append(a.shape[0])
+            xs = []
         for x in xs:
             if x is None:
                 ins.append(None); outs.append(None); frames.append(0); keep.append(None)
@@ -195,7 +218,10 @@ class Processor:
                 continue
             assert wr[l] == frames[l]
             res.append(np.array(k[1][: wr[l]], copy=True))
-        if pinned:
+        if slabs:
+            for arr in slabs:
+                L.lib().pipe_hip_host_free(C.c_void_p(arr.ctypes.data))
+        elif pinned:
             for k in keep:
                 if k is not None:
                     for arr in k:

@@ -77,7 +77,7 @@ def test_ragged_passes_advance_every_line_by_its_own_frames(pinned, dtype):
 
 # ---- large calls: chunks of Lines, H2D(k + 1) | kernels(k) | D2H(k - 1) ------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("entry", ["process", "process_lines"])
+@pytest.mark.parametrize("entry", ["process", "process_lines", "process_lines_pinned", "process_lines_slab"])
 def test_overlapped_chunks_of_lines_change_no_bit(entry, dtype, monkeypatch):
     """A call above PIPE_HIP_OVERLAP_MIN_BYTES is cut into chunks of whole Lines whose transfers and
     kernels overlap (abi.hip).  State is per Line, so the result must be the unchunked call's, bit for
@@ -102,7 +102,10 @@ def test_overlapped_chunks_of_lines_change_no_bit(entry, dtype, monkeypatch):
                     xs = [s[pos:pos + n].astype(dtype) for s in streams]
                     if k == 2:
                         xs[5] = None             # Line 5 has ended: its slot rides along as silence
-                    got = p.process_lines(xs)
+                    # (pinned rows: read and written in place -- one allocation per row by the row kernels, rows
+                    # carved from one block by the DMA engines while they are all there and equally long)
+                    got = p.process_lines(xs, pinned={"process_lines": False, "process_lines_pinned": True,
+                                                      "process_lines_slab": "slab"}[entry])
                     outs.append(np.stack([g if g is not None else np.zeros((n, Cb), dtype) for g in got]))
                 pos += n
             p.flush()
