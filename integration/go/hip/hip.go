@@ -231,6 +231,37 @@ func Resampler(proto []float64, tapsPerPhase, up, down int, o Options) *Stage {
 	}}
 }
 
+// FeedFor adapts a Source to an up-sampling Resampler further down its Line.  The pipe hands every component
+// buffers of the Line's bufferSize frames (pipe.go:90,107,437-443), so a stage that emits up/down times the
+// frames it reads fits its output only if it reads at most floor(bufferSize*down/up) of them: FeedFor allocates
+// the wrapped Source for that many frames and lets it fill only the head of the pipe's buffer -- a short read,
+// which the pipe carries on with (pipe.go:404-406: Slice(0, read)); every Processor behind it then sees
+// buffers the Resampler's output fits (3763 of 4096 frames at 44.1 -> 48 kHz).  For up <= down it returns the
+// Source unchanged.
+//
+//	pipe.Line{Source: hip.FeedFor(src, 160, 147), Processors: []pipe.ProcessorAllocatorFunc{rs.Allocator()}, Sink: sink}
+func FeedFor(src pipe.SourceAllocatorFunc, up, down int) pipe.SourceAllocatorFunc {
+	if up <= down {
+		return src
+	}
+	return func(mctx mutable.Context, bufferSize int) (pipe.Source, error) {
+		feed := bufferSize * down / up
+		if feed < 1 {
+			return pipe.Source{}, fmt.Errorf("hip.FeedFor: bufferSize %d too small for %d/%d", bufferSize, up, down)
+		}
+		s, err := src(mctx, feed)
+		if err != nil {
+			return pipe.Source{}, err
+		}
+		inner := s.SourceFunc
+		s.SourceFunc = func(out signal.Floating) (int, error) {
+			// the wrapped Source fills at most `feed` frames of the pipe's buffer
+			return inner(out.Slice(0, feed))
+		}
+		return s, nil
+	}
+}
+
 // Chain: several fixed-rate stages (Fir, Biquad, Gain) as ONE Processor whose intermediates stay
 // on the device (a Line's Processors slice, line.go:17, collapsed into one component).  The
 // stages' own Allocators must not be used as well.

@@ -500,7 +500,7 @@ public:
             return PIPE_HIP_EINVAL;  // window does not fit in LDS even at R = 1
         if (ols::Plan::supports(N_, cfg.channels)) {
             ols_.reset(new ols::Plan());
-            PH_TRY(ols_->init(cfg.device, taps, N_));
+            PH_TRY(ols_->init(cfg.device, taps, N_, cfg.channels));
         }
         return start(stream);
     }
@@ -647,7 +647,10 @@ public:
         v->taps = static_cast<const double *>(taps_[cur_taps_].p);
         v->ntaps = N_;
         v->relaxed = !exact_;
-        v->min_items = ols_min_items();
+        // (the fused chain replaces THREE launches and 4x the traffic: it pays from two transforms per CU, where the
+        // FIR alone needs eight to beat its direct form -- 64 Lines x 8 ch x 4096, a rank's share of configs[3] at
+        // 8 GPUs: 0.048 ms staged)
+        v->min_items = knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 2 * (int64_t)cus_;
         return true;
     }
     int fuse_commit_fir(hipStream_t s) override

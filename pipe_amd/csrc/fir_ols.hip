@@ -471,7 +471,7 @@ static void tap_spectrum(const double *taps, int N, double *out)
     out[2 * kHalf] = out[2 * kHalf + 1] = 0.0;  // the pad entry
 }
 
-int Plan::init(int device, const double *taps, int ntaps)
+int Plan::init(int device, const double *taps, int ntaps, int channels)
 {
     impl_->N = ntaps;
     hipDeviceProp_t prop;
@@ -504,7 +504,8 @@ int Plan::init(int device, const double *taps, int ntaps)
         // partitions of exactly 512 taps (the last one zero-padded): the hop of the frequency-domain
         // delay line; PIPE_HIP_FIR_PARTITION_SUM cuts them evenly for the sum-of-partitions kernel (A/B)
         impl_->P = (ntaps + 511) / 512;
-        impl_->Np = PH_ENV_AB("PIPE_HIP_FIR_PARTITION_SUM") ? (ntaps + impl_->P - 1) / impl_->P : 512;
+        // (the A/B kernel pairs channels: a one-channel stream has no pair to ride with and keeps the delay line)
+        impl_->Np = PH_ENV_AB("PIPE_HIP_FIR_PARTITION_SUM") && channels != 1 ? (ntaps + impl_->P - 1) / impl_->P : 512;
         const size_t pb = sizeof(double) * 2 * (kHalf + 1) * (size_t)impl_->P;
         PH_TRY(impl_->hpart[0].alloc(pb));
         PH_TRY(impl_->hpart[1].alloc(pb));

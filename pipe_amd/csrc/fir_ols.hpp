@@ -18,7 +18,7 @@ public:
 
     // taps the FFT path is built for (otherwise the direct form is used)
     static bool supports(int ntaps, int channels);
-    int init(int device, const double *taps, int ntaps);
+    int init(int device, const double *taps, int ntaps, int channels = 2);
     // double-buffered like the direct form's taps: queued launches keep the old spectrum; the
     // upload is asynchronous on `s` (the stream the handle's launches go to)
     int set_taps(const double *taps, hipStream_t s);
