@@ -15,7 +15,7 @@ run() { # tag kind [lib]
 run idle idle
 run ols ols
 for n in 1 2 3; do [ -f pipe_amd/lib/libpipe_hip_ols$n.so ] && run ols_ablate$n ols $PWD/pipe_amd/lib/libpipe_hip_ols$n.so; done
-PIPE_HIP_FIR_NO_MFMA=1 run direct direct   # the ordered-fma form on the VALU
+[ -f pipe_amd/lib/libpipe_hip_ab.so ] && PIPE_HIP_FIR_NO_MFMA=1 run direct direct $PWD/pipe_amd/lib/libpipe_hip_ab.so   # the ordered-fma form on the VALU (an A/B switch: the AB build)
 run mfma direct                            # ... and on the float64 matrix pipe (what large calls take)
 run gain gain
 run chain chain

@@ -31,7 +31,7 @@ else:
 global_pat = [pat]
 
 
-def mean_counter(sub, counter, largest_only=False):
+def mean_counter(sub, counter, largest_only=False, expect_kib=None):
     vals = []
     for p in glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True):
         db = sqlite3.connect(p)
@@ -44,14 +44,17 @@ def mean_counter(sub, counter, largest_only=False):
     if largest_only and vals:  # the bench kernel's own launches: the same kernel also runs the smaller c3_shape
         top = max(vals)
         vals = [v for v in vals if v >= 0.5 * top]
+    elif expect_kib and vals:  # the same kernel runs other objects of the line (the 64-Line resampler): this object's size only
+        vals = [v for v in vals if 0.4 < v / expect_kib < 2.5]
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
 def entry_for(kname, pat, workload, alg_bytes, largest_only=False):
     """HBM bytes per launch of the dispatches whose device kernel name matches `pat`."""
     global_pat[0] = pat
-    fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE", largest_only)
-    write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE", largest_only)
+    # (bytes in ~ bytes out ~ alg / 2; FETCH_SIZE counts half of the bytes read: bench.py live_pmc's filter)
+    fetch_kb, nf = mean_counter("pmc_fetch", "FETCH_SIZE", largest_only, alg_bytes / 4.0 / 1024.0)
+    write_kb, nw = mean_counter("pmc_write", "WRITE_SIZE", largest_only, alg_bytes / 2.0 / 1024.0)
     e = {
         "bench_kernel": kname,
         "device_kernel_regex": pat,
