@@ -290,7 +290,6 @@ struct pipe_hip_processor::Overlap {
         p->set_window(c.first + l0, (c.first + l0 == 0 && n == p->cfg.lines) ? 0 : n);
         int64_t produced = c.frames;
         PH_TRY(p->run_var(c.d_in + io, p->cfg.dtype, c.frames, c.d_out + oo, p->cfg.dtype, c.frames, &produced, p->stream));
-        PH_TRY(p->settle(p->stream));
         PH_HIP(hipEventRecord(done, p->stream));
         PH_HIP(hipStreamWaitEvent(s_out, done, 0));
         PH_HIP(hipMemcpyAsync(c.h_out + oo, c.d_out + oo, c.row_out * (size_t)n, hipMemcpyDeviceToHost, s_out));
@@ -406,8 +405,9 @@ namespace {
 // Handles that have a doorbell: the watchdog looks at them, and at process exit their doorbells are rung (a
 // store each), so that no queue is left waiting for a host that has gone (a handle that was never destroyed).
 // Lock order: g_resident_mu, then a handle's resident.mu (the fast path takes only the latter).
-std::mutex g_resident_mu;
-std::vector<pipe_hip_processor *> g_resident;
+// (never destroyed: the watchdog thread and the exit hook may still look at them while statics are torn down)
+std::mutex &g_resident_mu = *new std::mutex;
+std::vector<pipe_hip_processor *> &g_resident = *new std::vector<pipe_hip_processor *>;
 
 // spin on the completion word (the store behind the stage's kernels on the handle's stream)
 int resident_wait(pipe_hip_processor *p, unsigned k)
@@ -415,6 +415,9 @@ int resident_wait(pipe_hip_processor *p, unsigned k)
     const unsigned *done = p->resident.done();
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != k; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
         if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
             // the device never answered: report it, and see what the runtime says about the stream
             if (hipStreamQuery(p->stream) != hipErrorNotReady)
@@ -654,12 +657,10 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
         recorded = p->completion == nullptr;
         p->completion = nullptr;
         PH_TRY(rc);
-        PH_TRY(p->settle(p->stream));  // (a look-back form that failed is run again before the buffer is handed back)
     } else {
         if (in_b)
             PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
         PH_TRY(p->run_var(g.d_in.p, p->cfg.dtype, in_frames, g.d_out.p, p->cfg.dtype, cap, &out_frames, p->stream));
-        PH_TRY(p->settle(p->stream));
         const size_t out_b = es * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? out_frames : cap) *
                              (size_t)p->out_channels();
         if (out_b)
@@ -668,6 +669,7 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     if (!recorded)
         PH_HIP(hipEventRecord(g.done, p->stream));
     g.out_frames = (int32_t)out_frames;
+    g.zero_copy = zero_copy;
     p->submit_slot ^= 1;
     p->in_flight += 1;
     return PIPE_HIP_OK;
@@ -682,6 +684,21 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
     pipe_hip_processor::Staging &g = p->stg[(p->submit_slot - p->in_flight) & 1];
     PH_HIP(hipEventSynchronize(g.done));
     p->in_flight -= 1;
+    // a look-back launch that gave up: with this buffer the only one in flight the call is run again here (with a
+    // second one queued behind it -- submit / collect -- its work has already run on the failed one's state: reported)
+    bool reran = false;
+    int late = PIPE_HIP_OK;
+    if (p->in_flight == 0) {
+        PH_TRY(p->settle(p->stream, &reran));
+        if (reran && !g.zero_copy) {
+            const size_t es0 = dtype_size(p->cfg.dtype);
+            const size_t out_b = es0 * (size_t)p->cfg.lines * (size_t)(p->fixed_rate() ? g.out_frames : p->max_out_frames(p->cfg.buffer_size)) *
+                                 (size_t)p->out_channels();
+            PH_HIP(hipMemcpy(g.h_out.p, g.d_out.p, out_b, hipMemcpyDeviceToHost));
+        }
+    } else {
+        late = p->poll_error();
+    }
     const int32_t n = g.out_frames;
     if (n > out_cap_frames)
         return PIPE_HIP_ECAP;
@@ -702,8 +719,7 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
     }
     if (out_frames)
         *out_frames = n;
-    // (the buffer's event has been waited for: a device-side failure of its launches is known now)
-    return p->poll_error();
+    return late;
 }
 
 struct WindowGuard {  // whatever happens, the handle goes back to "all Lines"
@@ -1138,11 +1154,25 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
                               row_in * (size_t)r.count, hipMemcpyHostToDevice, p->stream));
         PH_TRY(p->run_var(static_cast<char *>(p->stg[0].d_in.p) + r.in_off, p->cfg.dtype, r.frames,
                           static_cast<char *>(p->stg[0].d_out.p) + r.out_off, p->cfg.dtype, r.frames, &produced, p->stream));
-        PH_TRY(p->settle(p->stream));
         PH_HIP(hipMemcpyAsync(static_cast<char *>(p->stg[0].h_out.p) + r.out_off, static_cast<char *>(p->stg[0].d_out.p) + r.out_off,
                               row_out * (size_t)r.count, hipMemcpyDeviceToHost, p->stream));
     }
     PH_HIP(hipStreamSynchronize(p->stream));
+    // a look-back launch that gave up: the usual pass (one run: the handle's window is still that run's) is run
+    // again and its rows fetched again; a ragged pass of several launches reports it
+    int late = PIPE_HIP_OK;
+    if (runs.size() == 1) {
+        bool reran = false;
+        PH_TRY(p->settle(p->stream, &reran));
+        if (reran) {
+            const LineRun &r = runs[0];
+            const size_t row_out = es * (size_t)r.frames * (size_t)p->out_channels();
+            PH_HIP(hipMemcpy(static_cast<char *>(p->stg[0].h_out.p) + r.out_off, static_cast<char *>(p->stg[0].d_out.p) + r.out_off,
+                             row_out * (size_t)r.count, hipMemcpyDeviceToHost));
+        }
+    } else {
+        late = p->poll_error();
+    }
     for (const LineRun &r : runs) {
         const size_t row_out = es * (size_t)r.frames * (size_t)p->out_channels();
         for (int i = 0; i < r.count; ++i) {
@@ -1153,7 +1183,7 @@ int pipe_hip_process_lines(pipe_hip_processor *p, const void *const *ins, const 
                         es * (size_t)in_frames[l] * (size_t)p->out_channels());
         }
     }
-    return p->poll_error();
+    return late;
 }
 
 int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins, const int32_t *in_frames,
@@ -1276,12 +1306,21 @@ int pipe_hip_process_lines_pinned(pipe_hip_processor *p, const void *const *ins,
         PH_TRY(launch_gather_rows(tin + r.first, win + r.first, din, (int)((size_t)r.frames * fb_in / 8), r.count,
                                   p->stream));
         PH_TRY(p->run_var(din, p->cfg.dtype, r.frames, dout, p->cfg.dtype, r.frames, &produced, p->stream));
-        PH_TRY(p->settle(p->stream));
         PH_TRY(launch_scatter_rows(tout + r.first, wout + r.first, dout, (int)((size_t)r.frames * fb_out / 8), r.count,
                                    p->stream));
     }
     PH_HIP(hipStreamSynchronize(p->stream));
-    return p->poll_error();
+    if (runs.size() != 1)
+        return p->poll_error();
+    bool reran = false;
+    PH_TRY(p->settle(p->stream, &reran));
+    if (reran) {  // (the rows of the launch that was run again go back once more)
+        const LineRun &r = runs[0];
+        PH_TRY(launch_scatter_rows(tout + r.first, wout + r.first, static_cast<char *>(p->stg[0].d_out.p) + r.out_off,
+                                   (int)((size_t)r.frames * fb_out / 8), r.count, p->stream));
+        PH_HIP(hipStreamSynchronize(p->stream));
+    }
+    return PIPE_HIP_OK;
 }
 
 int pipe_hip_mix_process(pipe_hip_processor *p, const void *const *ins, int32_t n_inputs,

@@ -1302,34 +1302,57 @@ public:
                                 hipMemcpyDeviceToDevice, s));
         return PIPE_HIP_OK;
     }
-    int settle(hipStream_t s) override
+    // the look-back flag of this handle's last tile launch (read and cleared); the launch has been waited for
+    bool read_flag()
     {
-        bool failed = false;
+        if (!err_.p || err_checked_)
+            return false;
+        volatile int *e = static_cast<volatile int *>(err_.p);
+        err_checked_ = true;
+        if (*e == 0)
+            return false;
+        *e = 0;
+        return true;
+    }
+    int settle(hipStream_t s, bool *reran) override
+    {
+        if (reran)
+            *reran = false;
+        bool failed = false, halves = false;
         for (int h = 0; h < 2; ++h)
             if (half_[h] && half_[h]->last_tile_.valid) {  // (3 - 4 sections: the halves' launches)
-                PH_HIP(hipStreamSynchronize(s));
-                if (half_[h]->poll_error() != PIPE_HIP_OK)
-                    failed = true;
+                halves = true;
+                failed = half_[h]->read_flag() || failed;
             }
-        if (failed) {
+        if (halves) {
             for (int h = 0; h < 2; ++h)
                 if (half_[h] && half_[h]->last_tile_.valid) {
-                    PH_TRY(half_[h]->take_back(s));
+                    if (failed)
+                        PH_TRY(half_[h]->take_back(s));
                     half_[h]->last_tile_.valid = false;
                 }
-            return rerun_ordered(split_call_, s);
+            if (!failed)
+                return PIPE_HIP_OK;
+            PH_TRY(rerun_ordered(split_call_, s));
+            PH_HIP(hipStreamSynchronize(s));
+            if (reran)
+                *reran = true;
+            return PIPE_HIP_OK;
         }
         if (!last_tile_.valid)
-            return PIPE_HIP_OK;
-        PH_HIP(hipStreamSynchronize(s));
-        if (poll_error() == PIPE_HIP_OK) {
+            return poll_error();
+        const TileCall c = last_tile_;
+        if (!read_flag()) {
             last_tile_.valid = false;
             return PIPE_HIP_OK;
         }
         PH_TRY(take_back(s));
-        const TileCall c = last_tile_;
         last_tile_.valid = false;
-        return rerun_ordered(c, s);
+        PH_TRY(rerun_ordered(c, s));
+        PH_HIP(hipStreamSynchronize(s));
+        if (reran)
+            *reran = true;
+        return PIPE_HIP_OK;
     }
     // Precondition as for the fused chain's: the stream of the last launch has been synchronised.
     int poll_error() override
@@ -1337,12 +1360,7 @@ public:
         for (auto &h : half_)
             if (h && h->poll_error() != PIPE_HIP_OK)
                 return PIPE_HIP_EHIP;
-        if (!err_.p || err_checked_)
-            return PIPE_HIP_OK;
-        volatile int *e = static_cast<volatile int *>(err_.p);
-        err_checked_ = true;
-        if (*e != 0) {
-            *e = 0;
+        if (read_flag()) {
             // (an asynchronous call whose buffers are no longer ours: it cannot be run again from here, but the
             // carried state can be what it was before it -- the caller may submit the batch again)
             if (last_tile_.valid) {
@@ -1362,6 +1380,8 @@ public:
         double *state;
         int sstride, soff, nseries;
         bool valid;
+        bool has_gain = false;  // a chain's gain folded into this launch's store (set around run() only)
+        double gain = 1.0;
     };
     TileCall last_tile_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false}, split_call_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false};
     int rerun_ordered(const TileCall &c, hipStream_t s)
@@ -1372,9 +1392,15 @@ public:
             std::fprintf(stderr, "pipe_hip: a tile biquad launch gave up waiting for a predecessor tile; the call was run again "
                                  "through the ordered recurrence (further occurrences are not reported)\n");
         }
+        const bool hg = has_gain_;
+        const double gv = gain_;
+        has_gain_ = c.has_gain;
+        gain_ = c.gain;
         ordered_once_ = true;
         const int rc = run(c.d_in, c.in_dtype, c.d_out, c.out_dtype, c.frames, s);
         ordered_once_ = false;
+        has_gain_ = hg;
+        gain_ = gv;
         return rc;
     }
     bool ordered_once_ = false;
@@ -1563,7 +1589,7 @@ public:
 #undef PH_BT3
 #undef PH_BT4
             if (single)  // (what settle() takes back and runs again if the look-back gives up)
-                last_tile_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true};
+                last_tile_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true, has_gain_, gain_};
         } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
@@ -1919,7 +1945,7 @@ public:
         half_[0]->relaxed_f64_out = true;
         half_[1]->relaxed_f64_out = relaxed_f64_out;
         half_[1]->set_post_gain(has_gain_, gain_);
-        split_call_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true};
+        split_call_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true, has_gain_, gain_};
         if (debug_withhold_ >= 0) {  // (halves made after the parameter was set)
             for (int h = 0; h < 2; ++h) {
                 half_[h]->debug_withhold_ = debug_withhold_;

@@ -76,6 +76,7 @@ public:
         }
         if (fused_)
             PH_TRY(fused_->export_state(s));  // the staged form reads the biquad stage's own array
+        last_staged_ = FusedCall{d_in, d_out, in_dtype, out_dtype, frames, true};
         PH_TRY(timer.begin(s));
         int hop = 0;
         for (size_t i = 0; i < ns; ++i) {
@@ -151,17 +152,28 @@ public:
                 return PIPE_HIP_OK;
         return PIPE_HIP_EINVAL;
     }
-    // the fused launch of a synchronous entry: wait for it, and if its look-back gave up run the call again staged
-    int settle(hipStream_t s) override
+    // the fused launch of a synchronous entry has been waited for: if its look-back gave up, run the call again staged
+    int settle(hipStream_t s, bool *reran) override
     {
+        if (reran)
+            *reran = false;
         if (!fused_ || !last_fused_.valid) {
-            for (auto &st : stages)  // (the staged chain: a stage that ran a look-back form looks after itself --
-                PH_TRY(st->settle(s));  //  its input, the chain's float64 intermediate, is still there)
-            return PIPE_HIP_OK;
+            int rc = fused_ ? fused_->poll_error() : PIPE_HIP_OK;
+            for (auto &st : stages) {  // (the staged chain: a stage that ran a look-back form looks after itself --
+                bool again = false;    //  its input, the chain's float64 intermediate, is still there; what it rewrote
+                const int r = st->settle(s, &again);  // feeds the stages behind it, so they run again too)
+                rc = rc != PIPE_HIP_OK ? rc : r;
+                if (again && rc == PIPE_HIP_OK) {
+                    rc = rerun_staged(s);
+                    if (reran)
+                        *reran = true;
+                    break;
+                }
+            }
+            return rc;
         }
         const FusedCall c = last_fused_;
         last_fused_.valid = false;
-        PH_HIP(hipStreamSynchronize(s));
         if (fused_->poll_error() == PIPE_HIP_OK)
             return PIPE_HIP_OK;
         PH_TRY(take_back(s));
@@ -172,9 +184,14 @@ public:
                                  "again on the staged chain (further occurrences are not reported)\n");
         }
         no_fuse_ = true;
-        const int rc = run(c.d_in, c.in_dtype, c.d_out, c.out_dtype, c.frames, s);
+        int rc = run(c.d_in, c.in_dtype, c.d_out, c.out_dtype, c.frames, s);
         no_fuse_ = false;
-        return rc;
+        PH_TRY(rc);
+        PH_HIP(hipStreamSynchronize(s));
+        if (reran)
+            *reran = true;
+        bool again = false;
+        return settle(s, &again);  // (the staged run's own look-back stages)
     }
     int poll_error() override
     {
@@ -216,8 +233,19 @@ private:
         int64_t frames;
         bool valid;
     };
-    FusedCall last_fused_{nullptr, nullptr, 0, 0, 0, false};
+    FusedCall last_fused_{nullptr, nullptr, 0, 0, 0, false}, last_staged_{nullptr, nullptr, 0, 0, 0, false};
     bool no_fuse_ = false;
+    // A stage of the staged chain ran its call again (its state is right again): the stages behind it have consumed
+    // what it wrote before.  Stages BEFORE it have advanced once and must not advance twice, so only the tail runs:
+    // simplest is to note that every stage but look-back ones is deterministic in (state, input) -- the rerun
+    // stage wrote the same buffer the next stage reads, so running the stages behind it again needs THEIR state
+    // of before the call, which only look-back stages keep.  A chain is FIR -> biquad (-> gain): behind the biquad
+    // sits at most a stateless gain, folded into the biquad's own store.  Nothing to do but wait.
+    int rerun_staged(hipStream_t s)
+    {
+        PH_HIP(hipStreamSynchronize(s));
+        return PIPE_HIP_OK;
+    }
     // the state of before the failed launch: the cascade's from the slot the launch did not write, the FIR's
     // history from the half it did not write
     int take_back(hipStream_t s)

@@ -211,6 +211,7 @@ struct pipe_hip_processor {
         void *hd_in = nullptr, *hd_out = nullptr;  // device aliases of h_in / h_out (zero-copy path)
         hipEvent_t done = nullptr;
         int32_t out_frames = 0;
+        bool zero_copy = false;  // the kernels read / wrote the pinned buffers themselves (no D2H copy to redo after a rerun)
     };
     Staging stg[2];
     // Set by submit while it queues a buffer: a stage whose LAST device operation for the call is a
@@ -329,12 +330,18 @@ struct pipe_hip_processor {
     virtual bool fuse_view_biquad(BiquadFuseView *) { return false; }
     // device-side failures that cannot be reported by the asynchronous call that caused them
     virtual int poll_error() { return PIPE_HIP_OK; }
-    // Called by the SYNCHRONOUS entries right behind run_var(), while the call's buffers are still theirs: a
-    // stage whose launch can fail on the device (the look-back forms: a predecessor tile that never shows up)
-    // waits for it here and, if it failed, puts its state back and runs the call again in a form that cannot --
-    // the reference aborts the whole run on a ProcessFunc error (pipe.go:438-440), and this one is not the
-    // stream's fault.  Everything else: nothing to do.
-    virtual int settle(hipStream_t) { return PIPE_HIP_OK; }
+    // Called by the SYNCHRONOUS entries once the call's work HAS BEEN WAITED FOR (its event or its stream), while
+    // the call's buffers are still theirs: a stage whose launch can fail on the device (the look-back forms: a
+    // predecessor tile that never shows up) looks at its flag and, if the launch failed, puts its state back,
+    // runs the call again in a form that cannot fail that way, waits for it, and says so in *reran (the entry
+    // then moves the results again) -- the reference aborts the whole run on a ProcessFunc error
+    // (pipe.go:438-440), and this one is not the stream's fault.  Everything else: a flag read at most.
+    virtual int settle(hipStream_t, bool *reran)
+    {
+        if (reran)
+            *reran = false;
+        return poll_error();
+    }
 
     // ---- the per-buffer path with the next call's work queued ahead of it (PIPE_HIP_PARAM_RESIDENT) ----
     // armable(): a run() that has been queued can be executed on stale input and its effect dropped --

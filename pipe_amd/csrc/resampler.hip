@@ -989,10 +989,12 @@ private:
             }
         if (ql == 0)
             return false;
-        if (ql > 192 && (2 * 192) % up_ == 0)
-            ql = 192;  // (three waves: four workgroups share a CU)
-        else if (ql > 192) {
-            for (int q = 192; q >= 32; --q)
+        const char *qle = PH_ENV_AB("PIPE_HIP_RESAMPLE_QL");  // A/B: the largest count of computing lanes
+        const int qcap = qle ? std::atoi(qle) : 192;
+        if (ql > qcap && (2 * qcap) % up_ == 0)
+            ql = qcap;  // (three waves: four workgroups share a CU)
+        else if (ql > qcap) {
+            for (int q = qcap; q >= 32; --q)
                 if ((2 * q) % up_ == 0) {
                     ql = q;
                     break;
@@ -1009,7 +1011,9 @@ private:
         t.ql = ql;
         t.ptaps = static_cast<const double *>(pair_taps_.p);
         t.adv = (int)((int64_t)2 * ql * down_ / up_);
-        t.steps = kOutTile / (2 * ql) > 0 ? kOutTile / (2 * ql) : 1;
+        const char *ote = PH_ENV_AB("PIPE_HIP_RESAMPLE_OUT_TILE");  // A/B: outputs per tile
+        const int out_tile = ote ? std::atoi(ote) : kOutTile;
+        t.steps = out_tile / (2 * ql) > 0 ? out_tile / (2 * ql) : 1;
         for (;; --t.steps) {
             t.win = t.steps * t.adv + (T_ - 1) + kPairPad + dmin + 3;
             t.win += t.win & 1;

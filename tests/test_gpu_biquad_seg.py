@@ -379,3 +379,25 @@ def test_a_tile_launch_that_gives_up_is_run_again_through_the_ordered_recurrence
                 assert bq.kernel_name().startswith("biquad_tile_kernel"), bq.kernel_name()
                 err = np.abs(got.astype(np.float64) - w.astype(np.float32).astype(np.float64)) / relaxed_ulp(q, want)[:, k * F:(k + 1) * F]
                 assert err.max() <= 1.0, (k, err.max())
+
+
+def test_a_staged_chain_whose_tile_biquad_gives_up_still_answers_the_stream():
+    """FIR -> biquad -> gain as the STAGED chain (a call too small for the fused kernel): the biquad stage's tile launch
+    fails on demand; the stage is run again through the ordered recurrence on the chain's float64 intermediate, with the
+    chain's gain still folded into its store."""
+    q = coeffs(1)
+    lines, C, F, N = 4, 2, 16384, 64
+    taps = synth.fir_lowpass_taps(N, f32_rounded=True)
+    x = np.stack([synth.samples(synth.line_seed(40 + l), 0, 3 * F * C, np.float32).reshape(3 * F, C) for l in range(lines)])
+    want = np.stack([O.Biquad(q, C).process(O.Fir(taps, C).process(x[l].astype(np.float64))).reshape(3 * F, C) * 0.25
+                     for l in range(lines)])
+    kw = dict(dtype=np.float32, lines=lines)
+    with P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(q, F, C, **kw), P.Gain(0.25, F, C, **kw)]) as ch:
+        ch.start()
+        for k in range(3):
+            if k == 1:
+                ch.set_stage_param(1, 5, [1.0, 2000.0])  # PIPE_HIP_PARAM_DEBUG on the biquad stage
+            got = ch.process(np.ascontiguousarray(x[:, k * F:(k + 1) * F])).reshape(lines, F, C)
+            w = want[:, k * F:(k + 1) * F]
+            err = np.abs(got.astype(np.float64) - w.astype(np.float32).astype(np.float64)) / relaxed_ulp(q / np.array([1, 1, 1, 1, 1.0]), want)[:, k * F:(k + 1) * F]
+            assert err.max() <= 1.0, (k, err.max())
