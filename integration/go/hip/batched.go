@@ -77,7 +77,9 @@ func (b *Batch) bind(mctx mutable.Context, bufferSize int, in pipe.SignalPropert
 		}
 		return nil
 	}
-	cfg := b.opts.config(bufferSize, in.Channels, b.lines)
+	o := b.opts
+	o.Float32 = false // (the batch's rows are the pipe's float64 samples, read and written in place)
+	cfg := o.config(bufferSize, in.Channels, b.lines)
 	chain, err := Chain(b.opts, b.stages...).create(&cfg)
 	if err != nil {
 		return err

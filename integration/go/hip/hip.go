@@ -44,6 +44,13 @@ import (
 // Options of every allocator.
 type Options struct {
 	Device int // HIP device ordinal; Line i of an n-GPU host takes i % n (SURVEY.md 8e)
+	// Float32: the samples cross PCIe and sit in HBM as float32 (BASELINE.json's north star: "interleaved
+	// multi-channel float32 buffers are DMA'd into HBM"; the pipe's own buffers stay signal.Floating = float64).
+	// Arithmetic stays float64; the result is within 1 ulp OF FLOAT32 of the float64 chain (the bound of
+	// PIPE_HIP_PARAM_EXACT in pipe_hip.h).  Half the bytes per call, and the forms that are float32-only apply:
+	// a biquad buffer costs 27 us instead of 100 (the ordered float64 recurrence is one wave's issue).  Default
+	// false: float64 buffers, bit for bit the oracle's float64 chain.
+	Float32 bool
 }
 
 // Stage is one GPU Processor: its allocator before the Line is bound, its handle afterwards.
@@ -55,7 +62,8 @@ type Stage struct {
 	p    *C.pipe_hip_processor
 	mctx mutable.Context // the context the pipe chose for this component (line.go:133-151
 	// overwrite whatever the allocator returns, so mutations must be made with THIS one)
-	inH, outH   []float64      // pinned staging, bufferSize * channels each
+	inH, outH   []float64      // pinned staging, bufferSize * channels each (Options.Float32: inF / outF instead)
+	inF, outF   []float32
 	inP, outP   unsafe.Pointer // their C addresses
 	outChannels int
 }
@@ -86,11 +94,18 @@ func doubles(v []float64) *C.double {
 	return (*C.double)(unsafe.Pointer(&v[0]))
 }
 
-// The pipe carries float64 buffers (pipe.go:394,437): dtype F64, one Line per handle.
+func (o Options) dtype() int {
+	if o.Float32 {
+		return C.PIPE_HIP_F32
+	}
+	return C.PIPE_HIP_F64
+}
+
+// The pipe carries float64 buffers (pipe.go:394,437): dtype F64 unless Options.Float32, one Line per handle.
 func (o Options) config(bufferSize, channels, lines int) C.pipe_hip_config {
 	return C.pipe_hip_config{
 		device: C.int32_t(o.Device), buffer_size: C.int32_t(bufferSize), channels: C.int32_t(channels),
-		dtype: C.PIPE_HIP_F64, lines: C.int32_t(lines), max_batch: 1,
+		dtype: C.int32_t(o.dtype()), lines: C.int32_t(lines), max_batch: 1,
 	}
 }
 
@@ -108,6 +123,29 @@ func write(src []float64, out signal.Floating) {
 	for i, v := range src {
 		out.SetSample(i, v)
 	}
+}
+
+// the same through float32 staging (Options.Float32): the one rounding of the input happens here
+func read32(in signal.Floating, dst []float32) int {
+	n := in.Length() * in.Channels()
+	for i := 0; i < n; i++ {
+		dst[i] = float32(in.Sample(i))
+	}
+	return in.Length()
+}
+
+func write32(src []float32, out signal.Floating) {
+	for i, v := range src {
+		out.SetSample(i, float64(v))
+	}
+}
+
+func pinned32(n int) ([]float32, unsafe.Pointer, error) {
+	var p unsafe.Pointer
+	if err := status(C.pipe_hip_host_alloc(C.int64_t(n*4), &p), "host_alloc"); err != nil {
+		return nil, nil, err
+	}
+	return unsafe.Slice((*float32)(p), n), p, nil
 }
 
 // Allocator is the pipe.ProcessorAllocatorFunc of this stage (line.go:26-30).  It may run while
@@ -128,11 +166,16 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 		// must not leak the device handle (Close frees whatever exists, nil pointers included)
 		s.p, s.mctx, s.outChannels = p, mctx, int(ch)
 		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
-		if s.inH, s.inP, err = pinned(bufferSize * in.Channels); err != nil {
-			s.Close()
-			return pipe.Processor{}, err
+		if s.opts.Float32 {
+			if s.inF, s.inP, err = pinned32(bufferSize * in.Channels); err == nil {
+				s.outF, s.outP, err = pinned32(bufferSize * int(ch))
+			}
+		} else {
+			if s.inH, s.inP, err = pinned(bufferSize * in.Channels); err == nil {
+				s.outH, s.outP, err = pinned(bufferSize * int(ch))
+			}
 		}
-		if s.outH, s.outP, err = pinned(bufferSize * int(ch)); err != nil {
+		if err != nil {
 			s.Close()
 			return pipe.Processor{}, err
 		}
@@ -151,13 +194,22 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 			// pipe.go:438: one buffer.  `in` is freed by the pipe right after the call
 			// (pipe.go:431) and must not be kept; `out` has Length() == bufferSize.
 			ProcessFunc: func(in, out signal.Floating) (int, error) {
-				n := read(in, s.inH)
+				var n int
+				if s.opts.Float32 {
+					n = read32(in, s.inF)
+				} else {
+					n = read(in, s.inH)
+				}
 				var written C.int32_t
 				st := C.pipe_hip_process(s.p, s.inP, C.int32_t(n), s.outP, C.int32_t(out.Length()), &written)
 				if err := status(st, "process"); err != nil {
 					return 0, err // the run ends with "error running: %w" (run.go:191-193)
 				}
-				write(s.outH[:int(written)*s.outChannels], out)
+				if s.opts.Float32 {
+					write32(s.outF[:int(written)*s.outChannels], out)
+				} else {
+					write(s.outH[:int(written)*s.outChannels], out)
+				}
 				return int(written), nil // pipe.go:441-443 slices out when written < bufferSize
 			},
 			FlushFunc: func(context.Context) error { return status(C.pipe_hip_flush(s.p), "flush") },
@@ -177,7 +229,7 @@ func (s *Stage) Close() {
 	// (pipe_hip_host_free accepts NULL: an allocator that failed half-way leaves one of them nil)
 	C.pipe_hip_host_free(s.inP)
 	C.pipe_hip_host_free(s.outP)
-	s.inP, s.outP, s.inH, s.outH = nil, nil, nil, nil
+	s.inP, s.outP, s.inH, s.outH, s.inF, s.outF = nil, nil, nil, nil, nil, nil
 }
 
 // ---- allocators -----------------------------------------------------------------------------
