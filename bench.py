@@ -453,7 +453,7 @@ def run_rank(args, rank, world, local, sync, launch):
     elapsed, kernel_ms, launches, kname = timed(proc, args.steps, args.warmup, d_in, d_out, frames_per_line,
                                                 barrier=True, call=main_calls)
     power = None
-    if rank == 0 and cfg == 1 and not args.no_power:
+    if rank == 0 and world == 1 and cfg == 1 and not args.no_power:  # (N = 1 only: no rank may trail the others into the group's teardown)
         # socket power and shader clock over a loaded window of the SAME launch (>= 2.5 s; hwmon, 10 ms
         # samples, the first fifth dropped): the headline kernel runs at the package power cap, and the
         # clock it is held at belongs next to the roofline fraction

@@ -64,8 +64,16 @@ for it in range(iters):
     ncalls = int(rng.integers(2, 9))
     lens = [int(rng.choice([F, F, F, 0, 1, 15, 16, 17, int(rng.integers(0, F + 1))])) for _ in range(ncalls)]
     x = rng.uniform(-1, 1, size=(sum(lens) + 1, C)).astype(np.float32).astype(dtype)
+    # (round 4) a float32 biquad buffer of >= 1024 frames takes the tile form, which is not bit-exact: this soak is
+    # about the ordered forms, so those handles are pinned to them; and every other armable handle (gain, FIR,
+    # FIR -> gain) runs with the next buffer's work queued behind a doorbell (PIPE_HIP_PARAM_RESIDENT)
+    resident = kind in ("fir", "gain") and C * F * np.dtype(dtype).itemsize <= (1 << 20) and rng.random() < 0.5
     with make() as p:
         p.start()
+        if kind in ("biquad", "chain"):
+            p.set_exact(True) if hasattr(p, "set_exact") else p._set_param(3, [1.0])
+        if resident:
+            p.set_resident(True)
         pos = 0
         i = 0
         while i < len(lens):
@@ -87,6 +95,6 @@ for it in range(iters):
                 buffers += 1
                 if a.shape != b.shape or not np.array_equal(a, b):
                     print("MISMATCH", dict(it=it, kind=kind, dtype=str(np.dtype(dtype)), C=C, F=F, ntaps=ntaps, S=S, lens=lens,
-                                           at=pos), flush=True)
+                                           at=pos, resident=bool(resident)), flush=True)
                     sys.exit(1)
 print(f"ok: {iters} random handles, {buffers} buffers bit-exact, {time.time() - t0:.1f} s")
