@@ -1,3 +1,4 @@
+#include <cstdlib>
 #include "hip_processors.hpp"
 
 #include <string>
@@ -69,6 +70,14 @@ error finish(pipe_hip_processor *raw, const SignalProperties &input, Processor *
     auto h = std::make_shared<Handle>(raw);
     if (handle)
         *handle = h;
+    // PIPE_HOST_RESIDENT (this harness's switch, what hip.Stage.SetResident is in the Go shim): every stage that can
+    // take a queued launch back keeps its next buffer's work queued behind a doorbell (PIPE_HIP_PARAM_RESIDENT);
+    // the others answer EINVAL and stay on the plain path.  The whole host-loop test suite then runs through it.
+    if (const char *e = std::getenv("PIPE_HOST_RESIDENT")) {
+        const double on = std::atof(e);
+        if (on != 0.0)
+            (void)pipe_hip_set_param(raw, PIPE_HIP_PARAM_RESIDENT, &on, 1);
+    }
     int32_t ch = 0, up = 1, down = 1;
     if (error e = StatusError(pipe_hip_output_properties(raw, &ch, &up, &down), "output_properties"))
         return e;

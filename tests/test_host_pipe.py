@@ -192,6 +192,21 @@ def test_hip_processor_error_surfaces_as_run_error():
     assert res[0].source.flushed and res[0].procs[0].flushed and res[0].sink.flushed
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_the_host_loop_through_the_resident_path(mode, monkeypatch):
+    """run.go:198-224's loop with every stage that can take a queued launch back (gain, FIR) keeping its NEXT buffer's
+    work queued on the device behind a doorbell (PIPE_HIP_PARAM_RESIDENT; the harness's PIPE_HOST_RESIDENT is what
+    hip.Stage.SetResident is in the Go shim): the same known answers, the same bits as the plain path -- short last
+    buffers, restarts between runs, an in-band mutation, an error that ends the run."""
+    monkeypatch.setenv("PIPE_HOST_RESIDENT", "1")
+    test_hip_copy_in_the_loop_config1(mode)
+    test_hip_fir_biquad_gain_lines_equal_oracle_loop(mode)
+    test_hip_fused_chain_equals_separate_stages_and_oracle()
+    test_mutation_reaches_hip_handle_through_the_message()
+    test_hip_processor_error_surfaces_as_run_error()
+
+
 # ---------------------------------------------------------- stage-major (batched) Run
 def test_run_batched_equals_run_without_groups():
     # no BatchGroup anywhere: the stage-major pass must give every Line what pipe.Run gives it
