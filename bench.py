@@ -634,6 +634,21 @@ def run_rank(args, rank, world, local, sync, launch):
             r4["msamples_per_s"] = round(n4 / (r4["ms_per_step"] * 1e-3) / 1e6, 1)
             r4["traffic"] = committed_traffic(r4["kernel"], n4 * bps)
             result["c4_chain"] = r4
+        # the same chain with 16 buffers per Line and launch (2 GiB per launch: streaming by its size): the kernel once a
+        # launch's edges -- everybody's first window at once, the last epilogue alone -- are amortised; it then sits at
+        # the socket's power cap (profiles/r04_chain_k_power.jsonl)
+        K16 = 16
+        n16 = L4 * K16 * F * C4
+        kw16 = dict(dtype=np_dtype, device=local, lines=L4, max_batch=K16)
+        if n16 <= min(ARENA, d_src.numel()):
+            with P.Chain([P.Fir(taps, F, C4, **kw16), P.Biquad(synth.biquad_rbj_lowpass(), F, C4, **kw16),
+                          P.Gain(0.7071067811865476, F, C4, **kw16)]) as ch16:
+                ch16.start()
+                _, k16, nl16, kn16 = timed(ch16, 40, 20, d_src[:n16], arena[:n16], K16 * F)
+                ms16 = k16 / max(nl16, 1)
+                result["c4_chain"]["steady_state_16_buffers_per_line"] = {
+                    "kernel": kn16, "avg_kernel_ms": round(ms16, 5), "algorithmic_bytes_per_launch": n16 * bps,
+                    "roofline_frac": round(n16 * bps / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
         # the biquad stage alone (no BASELINE config of its own; configs[3] runs it fused): the time-segmented
         # form through LDS tiles, one pass, on the configs[3] shape and on ONE stereo Line of the same sample count

@@ -66,6 +66,9 @@ def test_default_line_has_every_contract_field():
     for o in (c4, r5, c5["resampler_64_lines"], c5["mix"], d["biquad_alone"]["lines_512x8"], d["biquad_alone"]["one_stereo_line"]):
         assert o["sets"] >= 2 and o["sets"] * o["set_bytes"] >= 512 << 20
         assert 0 < o["roofline_frac"] < 0.85 and 0 < o["roofline_frac_l3_resident"] < 1.0
+    ss = c4["steady_state_16_buffers_per_line"]   # the chain once a launch's edges are amortised (2 GiB per launch)
+    assert ss["kernel"].startswith("chain_fused_kernel") and ss["algorithmic_bytes_per_launch"] == 16 * c4["algorithmic_bytes_per_launch"]
+    assert 0.15 < ss["roofline_frac"] < 0.5
     g = d["gain_reference"]
     assert g["kernel"].startswith("gain_kernel") and 0.5 < g["roofline_frac"] < 0.85   # (the guide's achievable HBM rate: ~0.79)
     # socket power and shader clock over a loaded window of the headline launch (hwmon; None where the box has no such node)
