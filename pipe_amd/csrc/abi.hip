@@ -434,16 +434,24 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
     pipe_hip_processor::Staging &g = p->stg[0];
     const unsigned k = R.seq + 1;
     PH_HIP(hipStreamWaitValue32(p->stream, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu));
-    int64_t out_frames = frames;
-    const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, p->stream);
-    // (whatever run_var did, the stream must not be left waiting for a doorbell nobody will ring for work that
-    // is not there: the completion store is queued in every case)
-    PH_HIP(hipStreamWriteValue32(p->stream, R.done(), k, 0));
+    // From here on the stream waits for doorbell value k: whatever fails below, somebody must ring it.
     R.seq = k;
     R.frames = frames;
-    R.out_frames = out_frames;
     R.armed_at = std::chrono::steady_clock::now();
     R.pending.store(true, std::memory_order_release);
+    int64_t out_frames = frames;
+    const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, p->stream);
+    R.out_frames = out_frames;
+    if (hipStreamWriteValue32(p->stream, R.done(), k, 0) != hipSuccess) {
+        // no completion word will ever be written for k: release the wait now and drain the stream the slow way
+        (void)hipGetLastError();
+        __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
+        R.pending.store(false, std::memory_order_release);
+        (void)hipStreamSynchronize(p->stream);
+        __atomic_store_n(R.done(), k, __ATOMIC_RELEASE);  // (what the missing store would have written)
+        p->rollback_launch();
+        return PIPE_HIP_EHIP;
+    }
     return rc;
 }
 // run what is queued on whatever the staging buffer holds, and take it back (resident.mu held)
