@@ -49,10 +49,23 @@ static pipe_hip_processor *make(int kind, const pipe_hip_config *cfg, const doub
         CHECK(pipe_hip_gain_create(cfg, 0.5, &p));
     } else if (kind == 1) {
         CHECK(pipe_hip_fir_create(cfg, taps, N, &p));
-    } else {
+    } else if (kind == 2) {
         CHECK(pipe_hip_fir_create(cfg, taps, N, &st[0]));
         CHECK(pipe_hip_gain_create(cfg, 0.5, &st[1]));
         CHECK(pipe_hip_chain_create(st, 2, &p));
+    } else {
+        /* RBJ low-pass, 1 kHz at 48 kHz, Q = 1/sqrt(2): {b0, b1, b2, a1, a2} */
+        const double w0 = 2 * 3.14159265358979323846 * 1000.0 / 48000.0, al = sin(w0) / (2 * 0.7071067811865476), a0 = 1 + al;
+        const double q[5] = {(1 - cos(w0)) / 2 / a0, (1 - cos(w0)) / a0, (1 - cos(w0)) / 2 / a0, -2 * cos(w0) / a0, (1 - al) / a0};
+        if (kind == 3) {
+            CHECK(pipe_hip_biquad_create(cfg, q, 1, &p));
+        } else {
+            pipe_hip_processor *s3[3];
+            CHECK(pipe_hip_fir_create(cfg, taps, N, &s3[0]));
+            CHECK(pipe_hip_biquad_create(cfg, q, 1, &s3[1]));
+            CHECK(pipe_hip_gain_create(cfg, 0.5, &s3[2]));
+            CHECK(pipe_hip_chain_create(s3, 3, &p));
+        }
     }
     CHECK(pipe_hip_start(p));
     return p;
@@ -61,7 +74,7 @@ static pipe_hip_processor *make(int kind, const pipe_hip_config *cfg, const doub
 int main(int argc, char **argv)
 {
     const int calls = argc > 1 ? atoi(argv[1]) : 3000, warm = 200;
-    static const char *names[3] = {"gain", "fir256", "chain fir256+gain"};
+    static const char *names[5] = {"gain", "fir256", "chain fir256+gain", "biquad", "chain fir256+biquad+gain"};
     double taps[N], sum = 0;
     for (int k = 0; k < N; ++k) {  /* a windowed sinc, normalised */
         const double t = k - (N - 1) / 2.0, w = 0.5 - 0.5 * cos(2 * 3.14159265358979323846 * k / (N - 1));
@@ -82,7 +95,7 @@ int main(int argc, char **argv)
         cfg.lines = 1;
         cfg.max_batch = 1;
         void *in = malloc(es * F * C), *out_a = malloc(es * F * C), *out_b = malloc(es * F * C);
-        for (int kind = 0; kind < 3; ++kind) {
+        for (int kind = 0; kind < 5; ++kind) {
             pipe_hip_processor *plain = make(kind, &cfg, taps), *res = make(kind, &cfg, taps);
             const double one = 1.0;
             CHECK(pipe_hip_set_param(res, PIPE_HIP_PARAM_RESIDENT, &one, 1));

@@ -94,8 +94,10 @@ typedef enum pipe_hip_param {
                                    path (4096 x 2 FIR-256: 24-26 us -> see DESIGN.md).  Depth per link stays
                                    fitting.go:56-60's: one buffer in the stage at a time, results bit for bit
                                    those of the plain path.  Opt-in per handle; stages whose state a queued
-                                   launch cannot be taken back from (biquad, resampler) and handles of many
-                                   Lines answer PIPE_HIP_EINVAL.  Idle cost: the queue's command processor
+                                   launch cannot be taken back from (the resampler, biquads of more than two
+                                   sections) and handles of many Lines answer PIPE_HIP_EINVAL; a biquad is
+                                   queued ahead for the calls that take its tile form (float32 buffers of
+                                   1024 frames or more) and runs the plain path for the others.  Idle cost: the queue's command processor
                                    polls one word; no compute unit is held.  The queued work assumes the
                                    frame count of the last call: a call that brings another count, a
                                    parameter mutation or any other entry on the handle first runs the queued

@@ -1016,8 +1016,10 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
             return p->poll_error();
         }
     }
+    // (a stage whose form depends on the call's size -- the biquad: the tile form can be taken back, the ordered
+    // recurrence cannot -- says per call whether its launch may be queued ahead; if not, the plain path below)
     if (p->resident.enabled && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
-        in_frames <= out_cap_frames) {
+        in_frames <= out_cap_frames && p->armable_for(in_frames, p->cfg.dtype)) {
         // The buffer's work is already on the device, behind the doorbell (queued while the last buffer ran):
         // copy in, ring, queue the NEXT buffer's work while this one runs, spin on the completion word.
         pipe_hip_processor::Resident &R = p->resident;

@@ -68,6 +68,7 @@ struct BiquadArgs {
     int blocks_per_seg;
     int sstride, soff;  // tile kernel, one pass: doubles between two series' states, and this cascade's first one (a cascade run as two halves)
     int spb;          // few series (< a workgroup's lanes): segments per workgroup, lanes = (segment, series); 0 = one segment
+    double *state_out;  // tile kernel, one pass: where a series' new state goes (a.state itself, or the other half of a double buffer)
 };
 
 // zero-input state transition over one segment, row-major (2S x 2S); a kernel argument, so the
@@ -715,8 +716,8 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 if (tile0_read) {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        a.state[series * a.sstride + a.soff + 2 * k] = s1[k];
-                        a.state[series * a.sstride + a.soff + 2 * k + 1] = s2[k];
+                        a.state_out[series * a.sstride + a.soff + 2 * k] = s1[k];
+                        a.state_out[series * a.sstride + a.soff + 2 * k + 1] = s2[k];
                     }
                 }
             }
@@ -1291,12 +1292,38 @@ public:
         pw_seg_ = -1;
         return PIPE_HIP_OK;
     }
+    // PIPE_HIP_PARAM_RESIDENT: a queued launch can be taken back when it is the one-pass tile form over all Lines
+    // (states out of place); the ordered forms update their states in place and cannot.  Whether a call takes that
+    // form depends on its frame count: armable_for() is asked per call.
+    bool armable() const override { return S_ <= kTileMaxSections && cfg.channels <= 8; }
+    bool armable_for(int64_t frames, int out_dtype) override
+    {
+        if (exact_ || env_exact_ || out_dtype != PIPE_HIP_F32 || !relaxed_ok() || windowed() || ext_state_)
+            return false;
+        const int64_t nseries = (int64_t)cfg.lines * cfg.channels;
+        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && nseries <= kTileLatencySeries;
+        return S_ <= kTileMaxSections && cfg.channels <= 8 && (frames * nseries >= seg_min_samples_ || long_few) &&
+               frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") && !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS") &&
+               !(cfg.channels >= kTileWalkChannels && cfg.lines >= tile_walk_lines_);
+    }
+    void rollback_launch() override
+    {
+        if (last_oop_) {
+            std::swap(state_.p, state_alt_.p);
+            last_oop_ = false;
+            last_tile_.valid = false;
+        }
+    }
     // The one-pass tile launch of a synchronous entry: wait for it; if a look-back gave up, the carried state goes
     // back to what tile 0 of every series read (the kernel keeps that copy) and the call runs again through the
     // ordered recurrence, which waits for nobody.
     int take_back(hipStream_t s)
     {
         const TileCall &c = last_tile_;
+        if (c.oop) {  // (the old states sit untouched in the other half)
+            std::swap(state_.p, state_alt_.p);
+            return PIPE_HIP_OK;
+        }
         const size_t w = sizeof(double) * 2u * (size_t)S_;
         PH_HIP(hipMemcpy2DAsync(c.state + c.soff, sizeof(double) * (size_t)c.sstride, state_bak_.p, w, w, (size_t)c.nseries,
                                 hipMemcpyDeviceToDevice, s));
@@ -1382,6 +1409,7 @@ public:
         bool valid;
         bool has_gain = false;  // a chain's gain folded into this launch's store (set around run() only)
         double gain = 1.0;
+        bool oop = false;       // the launch wrote the other half of the state double buffer (and the halves traded places)
     };
     TileCall last_tile_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false}, split_call_{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, false};
     int rerun_ordered(const TileCall &c, hipStream_t s)
@@ -1445,6 +1473,7 @@ public:
         // (the relaxed forms carry states through powers of the transition matrix: stable sections only)
         const bool relaxed = !exact_ && !env_exact_ && !ordered_once_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && relaxed_ok();
         last_tile_.valid = false;
+        last_oop_ = false;
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
         bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
                          frames * a.nseries >= seg_min_samples_;
@@ -1471,6 +1500,7 @@ public:
         // kTileLatencyFrames or more frames in one short launch (4096 x 2: 12.8 us); PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES
         // set in the environment is the only rule when it is there.
         const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && a.nseries <= kTileLatencySeries;
+        a.state_out = a.state;
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
                            frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") &&
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
@@ -1521,6 +1551,16 @@ public:
             BiquadLookArgs lk{};
             if (ext_state_ && !single)
                 return PIPE_HIP_EINVAL;
+            // One pass over ALL of the handle's Lines: the new states go to the other half of a double buffer and the
+            // halves trade places -- a launch that is taken back (a look-back that gave up, queued work of the resident
+            // path that is dropped) then left the old states untouched.  (A window of Lines, or a half of a longer
+            // cascade working on its parent's array, writes in place and keeps the copy tile 0 makes.)
+            const bool oop = single && !windowed() && !ext_state_;
+            if (oop) {
+                if (!state_alt_.p)
+                    PH_TRY(state_alt_.alloc(state_bytes_));
+                a.state_out = static_cast<double *>(state_alt_.p);
+            }
             if (single) {
                 PH_TRY(prepare_look(&lk, a, seg, nl, tgrid.x, s));
             } else {
@@ -1589,7 +1629,10 @@ public:
 #undef PH_BT3
 #undef PH_BT4
             if (single)  // (what settle() takes back and runs again if the look-back gives up)
-                last_tile_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true, has_gain_, gain_};
+                last_tile_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true, has_gain_, gain_, oop};
+            if (oop)
+                std::swap(state_.p, state_alt_.p);
+            last_oop_ = oop;
         } else if (segmented) {
             const size_t need = sizeof(double) * (size_t)a.T * (size_t)a.nseries * (size_t)S_ * 2u;
             if (seg_.bytes < need)
@@ -2126,7 +2169,8 @@ private:
     bool has_gain_ = false;
     double gain_ = 1.0;
     BiquadCoeffs q_{};
-    DevBuf state_, seg_;
+    DevBuf state_, seg_, state_alt_;
+    bool last_oop_ = false;
     size_t state_bytes_ = 0;
     bool exact_ = false;
     const bool env_exact_ = std::getenv("PIPE_HIP_BIQUAD_EXACT") != nullptr;

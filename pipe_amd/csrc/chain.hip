@@ -124,6 +124,23 @@ public:
                 return false;
         return !stages.empty();
     }
+    bool armable_for(int64_t frames, int out_dtype) override
+    {
+        // (the dtypes a stage sees inside run(): float64 between stages, the chain's own at its end; a gain behind a
+        // biquad is folded into the biquad's store)
+        const size_t ns = stages.size();
+        for (size_t i = 0; i < ns; ++i) {
+            double g;
+            const bool fold = i + 1 < ns && gain_value(stages[i + 1].get(), &g) && biquad_set_post_gain(stages[i].get(), false, 1.0);
+            const size_t done = fold ? i + 1 : i;
+            const bool last = done + 1 == ns;
+            stages[i]->relaxed_f64_out = !last && out_dtype == PIPE_HIP_F32;
+            if (!stages[i]->armable_for(frames, last ? out_dtype : (int)PIPE_HIP_F64))
+                return false;
+            i = done;
+        }
+        return ns > 0;
+    }
     void rollback_launch() override
     {
         for (auto &st : stages)

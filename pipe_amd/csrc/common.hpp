@@ -348,6 +348,9 @@ struct pipe_hip_processor {
     // the stage is stateless, or its state is double-buffered and rollback_launch() points it back at the
     // half the dropped launch did not write.  Stages that update state in place answer false.
     virtual bool armable() const { return false; }
+    // ... for a call of `frames` frames whose results leave the stage as out_dtype (a stage whose form -- and with it
+    // whether the launch can be taken back -- depends on the call's size)
+    virtual bool armable_for(int64_t /*frames*/, int /*out_dtype*/) { return armable(); }
     virtual void rollback_launch() {}
     struct Resident {
         bool enabled = false;

@@ -95,11 +95,52 @@ def test_chain_of_fir_and_gain_restart_and_other_entries():
         assert np.array_equal(got, want)
 
 
+def test_a_biquad_is_queued_ahead_for_the_calls_that_take_its_tile_form():
+    """The tile form writes a series' new state out of place (the halves of a double buffer trade places), so a queued
+    launch can be taken back; the ordered recurrence updates its state in place and cannot.  float32 buffers of >= 1024
+    frames: queued ahead, bit for bit the plain path's tile form; a short buffer in between and float64 buffers run the
+    plain path (ordered, bit for bit the oracle) on the same handle."""
+    q = synth.biquad_rbj_lowpass()
+    taps = synth.fir_lowpass_taps(64)
+    x = stream(9, 8)
+    for mk in (lambda dt: P.Biquad(q, F, C, dtype=dt),
+               lambda dt: P.Chain([P.Fir(taps, F, C, dtype=dt), P.Biquad(q, F, C, dtype=dt), P.Gain(0.5, F, C, dtype=dt)])):
+        with mk(np.float32) as res, mk(np.float32) as plain:
+            res.start()
+            plain.start()
+            res.set_resident(True)
+            for k in range(8):
+                frames = 300 if k == 3 else (2000 if k == 5 else F)   # (300: the ordered form; 2000: another tile call)
+                if k == 6:
+                    for h in (res, plain):
+                        h.set_stage_param(1, L.PARAM_COEFFS, synth.biquad_rbj_lowpass(fc=3000.0)) if hasattr(h, "stages") \
+                            else h.set_coeffs(synth.biquad_rbj_lowpass(fc=3000.0))
+                xin = x[k, :frames].astype(np.float32)
+                assert np.array_equal(res.process(xin), plain.process(xin)), k
+        with mk(np.float64) as r64:
+            r64.start()
+            r64.set_resident(True)
+            refs = [O.Biquad(q, C)] if not hasattr(r64, "stages") else [O.Fir(taps, C), O.Biquad(q, C)]
+            for k in range(3):
+                y = x[k]
+                for r in refs:
+                    y = np.asarray(r.process(y)).reshape(F, C)
+                if hasattr(r64, "stages"):
+                    y = y * 0.5
+                assert np.array_equal(r64.process(x[k]), y), k
+
+
 def test_stages_with_in_place_state_and_many_lines_are_turned_away():
-    with P.Biquad(synth.biquad_rbj_lowpass(), F, C, dtype=np.float32) as bq:
+    three = np.vstack([synth.biquad_rbj_lowpass(fc=f) for f in (500.0, 1500.0, 4000.0)])
+    with P.Biquad(three, F, C, dtype=np.float32) as bq:   # (the tile form holds two sections)
         bq.start()
         with pytest.raises(L.PipeHipError):
             bq.set_resident(True)
+    proto = synth.resampler_proto(160, 147, 24)
+    with P.Resampler(proto, 24, 160, 147, F, C, dtype=np.float32) as rs:
+        rs.start()
+        with pytest.raises(L.PipeHipError):
+            rs.set_resident(True)
     with P.Gain(0.5, 4096, 8, dtype=np.float32, lines=512) as g:  # 64 MiB a buffer: not the zero-copy path
         g.start()
         with pytest.raises(L.PipeHipError):
