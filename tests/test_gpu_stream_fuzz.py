@@ -27,8 +27,11 @@ def lengths(rng, F, calls):
     return [int(rng.choice(pool)) if rng.random() < 0.5 else int(rng.integers(0, F + 1)) for _ in range(calls)]
 
 
+@pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("seed", range(12))
-def test_fir_stream_fuzz(seed):
+def test_fir_stream_fuzz(seed, resident):
+    # (resident: the same streams with the next buffer's work queued behind a doorbell, PIPE_HIP_PARAM_RESIDENT --
+    # every length change, the reset and the mutation then find queued work to take back)
     rng = np.random.default_rng(1000 + seed)
     C = int(rng.choice([1, 2, 3, 6, 8, 17]))
     F = int(rng.choice([64, 257, 512, 4096]))
@@ -44,6 +47,8 @@ def test_fir_stream_fuzz(seed):
     ref = O.Fir(h1, C)
     with P.Fir(h1, F, C, dtype=dtype) as p:
         p.start()
+        if resident:
+            p.set_resident(True)
         for k, n in enumerate(lens):
             if k == reset_at:
                 p.start()
