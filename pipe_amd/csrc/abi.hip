@@ -427,13 +427,17 @@ int resident_wait(pipe_hip_processor *p, unsigned k)
     }
     return PIPE_HIP_OK;
 }
+constexpr int kResidentUnsupported = -1000;  // resident_arm: the stream wait could not be queued (not an ABI status)
 // queue the work of a buffer of `frames` frames behind the next doorbell value (resident.mu held)
 int resident_arm(pipe_hip_processor *p, int32_t frames)
 {
     pipe_hip_processor::Resident &R = p->resident;
     pipe_hip_processor::Staging &g = p->stg[0];
     const unsigned k = R.seq + 1;
-    PH_HIP(hipStreamWaitValue32(p->stream, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    if (hipStreamWaitValue32(p->stream, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) {
+        (void)hipGetLastError();  // (a platform without stream memory operations: nothing was queued)
+        return kResidentUnsupported;
+    }
     // From here on the stream waits for doorbell value k: whatever fails below, somebody must ring it.
     R.seq = k;
     R.frames = frames;
@@ -1027,8 +1031,14 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         std::lock_guard<std::mutex> lk(R.mu);  // (the watchdog keeps its hands off until the result is out)
         if (R.pending.load() && R.frames != in_frames)
             PH_TRY(resident_cancel_locked(p));  // (a short buffer: pipe.go:441-443)
-        if (!R.pending.load())
-            PH_TRY(resident_arm(p, in_frames));  // the first call, or the one after a cancellation
+        if (!R.pending.load()) {  // the first call, or the one after a cancellation
+            const int rc0 = resident_arm(p, in_frames);
+            if (rc0 == kResidentUnsupported) {  // no stream memory operations here: the plain path from now on
+                R.enabled = false;
+                goto plain_path;
+            }
+            PH_TRY(rc0);
+        }
         pipe_hip_processor::Staging &g = p->stg[0];
         const size_t es = dtype_size(p->cfg.dtype);
         std::memcpy(g.h_in.p, in, es * (size_t)in_frames * (size_t)p->cfg.channels * (size_t)p->cfg.lines);
@@ -1036,7 +1046,11 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         const int64_t produced = R.out_frames;
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
         R.pending.store(false);
-        const int rc_next = resident_arm(p, in_frames);
+        int rc_next = resident_arm(p, in_frames);
+        if (rc_next == kResidentUnsupported) {  // (it worked a call ago: treat as a runtime error of this call's successor)
+            R.enabled = false;
+            rc_next = PIPE_HIP_OK;
+        }
         PH_TRY(resident_wait(p, k));
         std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
         if (out_frames)
@@ -1044,6 +1058,7 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         PH_TRY(rc_next);
         return p->poll_error();
     }
+plain_path:
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
     return collect_impl(p, out, out_cap_frames, out_frames);
 }
