@@ -39,7 +39,10 @@ typedef enum pipe_hip_status {
     PIPE_HIP_EHIP = 3,     /* a HIP runtime call failed; pipe_hip_last_hip_error() has the code */
     PIPE_HIP_ENOMEM = 4,
     PIPE_HIP_ECAP = 5,     /* output would exceed out_cap_frames (pipe.go:437-443: out is bufferSize) */
-    PIPE_HIP_ESTATE = 6    /* call out of order (e.g. collect without submit) */
+    PIPE_HIP_ESTATE = 6,   /* call out of order (e.g. collect without submit; process after a queued launch failed on
+                              the device and before the next StartFunc) */
+    PIPE_HIP_EBUSY = 7     /* PIPE_HIP_PARAM_RESIDENT: another handle holds this device's doorbell; the handle stays on
+                              the plain path (not an error of the stream) */
 } pipe_hip_status;
 
 typedef enum pipe_hip_dtype {
@@ -90,24 +93,40 @@ typedef enum pipe_hip_param {
                                    to the data): behind a wait on a doorbell word in pinned host memory sit the
                                    stage's kernels and a store to a completion word.  pipe_hip_process then
                                    copies the buffer into the pinned staging area, rings the doorbell, queues
-                                   the work of the call after this one while the device runs, and spins on the
+                                   the work of the call after this one while the device runs, and waits for the
                                    completion word -- no kernel launch and no completion event on the call's
-                                   path (4096 x 2 FIR-256: 24-26 us -> see DESIGN.md).  Depth per link stays
+                                   path (per-call figures: DESIGN.md section 5).  Depth per link stays
                                    fitting.go:56-60's: one buffer in the stage at a time, results bit for bit
-                                   those of the plain path.  Opt-in per handle; stages whose state a queued
-                                   launch cannot be taken back from (the resampler, biquads of more than two
-                                   sections) and handles of many Lines answer PIPE_HIP_EINVAL; a biquad is
-                                   queued ahead for the calls that take its tile form (float32 buffers of
-                                   1024 frames or more) and runs the plain path for the others.  Idle cost: the queue's command processor
-                                   polls one word; no compute unit is held.  The queued work assumes the
-                                   frame count of the last call: a call that brings another count, a
-                                   parameter mutation or any other entry on the handle first runs the queued
-                                   work on stale input and discards it (one wasted round trip).  A queue that
-                                   waits for a doorbell holds up device-wide synchronisations of the process
-                                   (hipDeviceSynchronize), so queued work is also discarded -- by a watchdog
-                                   thread of the library -- when no call has come for 250 ms (a value above 1:
-                                   that many milliseconds); pipe_hip_destroy of any handle discards what is
-                                   queued on its device before it waits for the device. */
+                                   those of the plain path.
+                                   ONE handle per device can hold the doorbell (a queue that waits for a doorbell
+                                   costs every other waiting queue of the process tens of microseconds, and a wait
+                                   in a shared hardware queue holds up other handles' kernels: measured,
+                                   DESIGN.md section 5); the holder's work runs on a stream with a hardware queue of
+                                   its own.  A second handle that asks is answered PIPE_HIP_EBUSY and stays on
+                                   the plain path; value 0 gives the doorbell back (so does pipe_hip_destroy).
+                                   Stages whose state a queued launch cannot be taken back from (the resampler,
+                                   biquads of more than two sections) and handles of many Lines answer
+                                   PIPE_HIP_EINVAL; a biquad is queued ahead for the calls that take its tile
+                                   form (float32 buffers of 1024 frames or more) and runs the plain path for
+                                   the others.
+                                   Costs.  Idle: the doorbell queue's command processor polls one word; no
+                                   compute unit is held.  Busy: the calling thread spins on the completion word
+                                   for the length of the stage's kernels (pause, then yield after 50 us, then
+                                   50 us sleeps after 2 ms) -- one host core per call in flight, as with the
+                                   plain path's completion word.  The queued work assumes the frame count of the
+                                   last call: a call that brings another count, a parameter mutation or any
+                                   other entry on the handle first runs the queued work on stale input and
+                                   drops it (one wasted round trip).  A queue that waits for a doorbell holds up
+                                   every device-wide wait of the process (hipDeviceSynchronize, hipFree, work on
+                                   the null stream), so queued work is also dropped -- by a watchdog thread of
+                                   the library, which only rings and never waits -- when no call has come for
+                                   250 ms (a value above 1: that many milliseconds), and by pipe_hip_destroy of
+                                   any handle of the device.  Dropped launches are counted: pipe_hip_resident_info.
+                                   A queued launch that fails on the device (a look-back wait that gives up, see
+                                   PIPE_HIP_PARAM_DEBUG) cannot be run again in another form as on the plain path
+                                   -- its successor is already queued on its state: pipe_hip_process answers
+                                   PIPE_HIP_EHIP (a ProcessFunc error ends the run, pipe.go:438-440) and
+                                   PIPE_HIP_ESTATE until the next pipe_hip_start. */
     PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
                                   biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
                                   up after limit_us -- the failure a preempted predecessor tile causes.  A
@@ -261,6 +280,13 @@ int pipe_hip_set_profiling(pipe_hip_processor *p, int32_t enabled);
 int pipe_hip_kernel_time(pipe_hip_processor *p, double *total_ms, int64_t *launches, int32_t reset);
 /* name of the dominant kernel variant the last batch call launched */
 const char *pipe_hip_kernel_name(const pipe_hip_processor *p);
+/* PIPE_HIP_PARAM_RESIDENT bookkeeping: *holds_doorbell = 1 while the handle holds its device's doorbell;
+ * *dropped_by_watchdog / *dropped_by_entry = queued launches that were run on stale input and taken back because
+ * no call came within the idle limit / because another entry (a mutation, a short buffer, start, flush, another
+ * handle's destroy) came first.  A host that sees dropped_by_watchdog grow is feeding the stage slower than the
+ * idle limit: each drop is one wasted round trip on the next call.  Any pointer may be NULL. */
+int pipe_hip_resident_info(pipe_hip_processor *p, int32_t *holds_doorbell, int64_t *dropped_by_watchdog,
+                           int64_t *dropped_by_entry);
 
 /* ---- utilities ------------------------------------------------------------------ */
 int pipe_hip_abi_version(void);

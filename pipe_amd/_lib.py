@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIPE_HIP_LIB: an alternative build of the same library (A/B runs of kernel variants)
 LIB_PATH = os.environ.get("PIPE_HIP_LIB") or os.path.join(_HERE, "lib", "libpipe_hip.so")
 
-OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE = range(7)
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE, EBUSY = range(8)
 F32, F64 = 0, 1
-PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS, PARAM_EXACT, PARAM_RESIDENT = 0, 1, 2, 3, 4
+PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS, PARAM_EXACT, PARAM_RESIDENT, PARAM_DEBUG = 0, 1, 2, 3, 4, 5
 
 
 class Config(C.Structure):
@@ -117,6 +117,7 @@ def lib():
         "pipe_hip_set_profiling": (C.c_int, [vp, i32]),
         "pipe_hip_kernel_time": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i64), i32]),
         "pipe_hip_kernel_name": (C.c_char_p, [vp]),
+        "pipe_hip_resident_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "pipe_hip_host_alloc": (C.c_int, [i64, hp]),
         "pipe_hip_host_free": (C.c_int, [vp]),
         "pipe_hip_synth_fill": (C.c_int, [i32, vp, i32, C.c_uint64, i64, i64, vp]),

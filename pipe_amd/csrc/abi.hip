@@ -19,6 +19,7 @@
 namespace pipehip {
 
 thread_local int g_last_hip_error = 0;
+thread_local std::vector<DeferredFree> *g_deferred_frees = nullptr;
 
 // ---- KernelTimer -------------------------------------------------------------
 KernelTimer::~KernelTimer()
@@ -401,34 +402,70 @@ struct pipe_hip_processor::Overlap {
 
 // ---- shared handle plumbing ---------------------------------------------------
 // ---- PIPE_HIP_PARAM_RESIDENT: the next buffer's work queued on the device ahead of its call ------------------
+// Round 4 parked a wait packet (hipStreamWaitValue32) on every resident handle's own stream.  What that does on this
+// runtime (scripts/micro/queue_independence.hip, profiles/r05_queue_independence.txt):
+//  * HIP deals streams onto FOUR hardware queues; with 16 streams parked only the 4 at the heads of the queues ever
+//    answer their doorbell -- a handle's kernels sit behind another handle's wait until a watchdog rings that one
+//    (the async host loop: one 250 ms / 10 s rescue after the other -- GPUTEST_r04's 1200 s);
+//  * a stream made with hipExtStreamCreateWithCUMask has a hardware queue of its own (16 of 16 and 40 of 40 answer),
+//    but making one after another one was DESTROYED hangs now and then, so such a stream is made once and kept;
+//  * every other parked queue costs the one that is rung: doorbell -> completion 9 us alone, 42 us next to ONE other
+//    parked queue, 91 us next to two, 108 next to six -- against 12 us for launch + completion word with nothing parked.
+// So: ONE doorbell per device.  The handle that holds it runs on the device's doorbell stream (own hardware queue,
+// made on first use, never destroyed); a second handle that asks is answered PIPE_HIP_EBUSY and stays on the plain
+// path, which completes by a word in pinned memory as well (express completion, below) and parks nothing.
+// Nobody waits for the device while holding a lock another thread needs in order to ring: foreign threads (watchdog,
+// another handle about to free memory or to wait for the whole device) try the handle's lock, ring, mark the work
+// stale and leave; the owner waits for its own stale work and takes it back at its next entry.
 namespace {
-// Handles that have a doorbell: the watchdog looks at them, and at process exit their doorbells are rung (a
-// store each), so that no queue is left waiting for a host that has gone (a handle that was never destroyed).
-// Lock order: g_resident_mu, then a handle's resident.mu (the fast path takes only the latter).
+constexpr int kMaxDevices = 64;
+struct Door {
+    pipe_hip_processor *owner = nullptr;  // the handle that holds this device's doorbell
+    hipStream_t stream = nullptr;         // hardware queue of its own; made once, never destroyed
+};
 // (never destroyed: the watchdog thread and the exit hook may still look at them while statics are torn down)
-std::mutex &g_resident_mu = *new std::mutex;
-std::vector<pipe_hip_processor *> &g_resident = *new std::vector<pipe_hip_processor *>;
+std::mutex &g_door_mu = *new std::mutex;  // guards g_door[].owner; lock order: g_door_mu, then TRY a handle's resident.mu
+Door *g_door = new Door[kMaxDevices];
 
-// spin on the completion word (the store behind the stage's kernels on the handle's stream)
-int resident_wait(pipe_hip_processor *p, unsigned k)
+// Wait for a word in coherent pinned memory to become k: pause-spin for the length of a per-buffer kernel, then
+// yield the core, then sleep in 50 us steps (a host core spins per call in flight, for at most ~50 us).
+bool wait_word(const unsigned *w, unsigned k, std::chrono::milliseconds limit)
 {
-    const unsigned *done = p->resident.done();
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == k)
+        return true;
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != k; ++spins) {
+    for (unsigned spins = 1;; ++spins) {
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
-        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
-            // the device never answered: report it, and see what the runtime says about the stream
-            if (hipStreamQuery(p->stream) != hipErrorNotReady)
-                (void)hipGetLastError();
-            return PIPE_HIP_EHIP;
-        }
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == k)
+            return true;
+        if ((spins & 31u) != 0)
+            continue;
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > limit)
+            return false;
+        if (dt > std::chrono::milliseconds(2))
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (dt > std::chrono::microseconds(50))
+            std::this_thread::yield();
     }
-    return PIPE_HIP_OK;
+}
+
+// the completion word of doorbell k (the bell HAS been rung: the stream cannot wait for anything of ours any more)
+int resident_wait(pipe_hip_processor *p, unsigned k)
+{
+    if (wait_word(p->resident.done(), k, std::chrono::milliseconds(10000)))
+        return PIPE_HIP_OK;
+    // ten seconds: a device busy with somebody else's work, or gone.  The runtime's own wait ends either way.
+    if (hipStreamSynchronize(p->stream) != hipSuccess) {
+        g_last_hip_error = (int)hipGetLastError();
+        return PIPE_HIP_EHIP;
+    }
+    return __atomic_load_n(p->resident.done(), __ATOMIC_ACQUIRE) == k ? PIPE_HIP_OK : PIPE_HIP_EHIP;
 }
 constexpr int kResidentUnsupported = -1000;  // resident_arm: the stream wait could not be queued (not an ABI status)
-// queue the work of a buffer of `frames` frames behind the next doorbell value (resident.mu held)
+// queue the work of a buffer of `frames` frames behind the next doorbell value (resident.mu held, state idle)
 int resident_arm(pipe_hip_processor *p, int32_t frames)
 {
     pipe_hip_processor::Resident &R = p->resident;
@@ -438,35 +475,49 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
         (void)hipGetLastError();  // (a platform without stream memory operations: nothing was queued)
         return kResidentUnsupported;
     }
-    // From here on the stream waits for doorbell value k: whatever fails below, somebody must ring it.
+    // From here on the stream waits for doorbell value k: whatever fails below, somebody must ring it -- and nothing
+    // below may wait for the device (no synchronisation, no hipFree: g_deferred_frees, queued_run).
     R.seq = k;
     R.frames = frames;
     R.armed_at = std::chrono::steady_clock::now();
-    R.pending.store(true, std::memory_order_release);
+    R.state.store(pipe_hip_processor::Resident::kArmed, std::memory_order_release);
     int64_t out_frames = frames;
+    g_deferred_frees = &R.frees;
+    p->queued_run = true;
     const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, p->stream);
+    p->queued_run = false;
+    g_deferred_frees = nullptr;
     R.out_frames = out_frames;
-    if (hipStreamWriteValue32(p->stream, R.done(), k, 0) != hipSuccess) {
-        // no completion word will ever be written for k: release the wait now and drain the stream the slow way
-        (void)hipGetLastError();
+    const hipError_t we = hipStreamWriteValue32(p->stream, R.done(), k, 0);
+    if (we != hipSuccess || rc != PIPE_HIP_OK) {
+        // the queued work is incomplete (or no completion word will be written for k): release the wait now, drain the
+        // stream the slow way and take back whatever part of the launch was queued
+        if (we != hipSuccess)
+            (void)hipGetLastError();
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
-        R.pending.store(false, std::memory_order_release);
         (void)hipStreamSynchronize(p->stream);
         __atomic_store_n(R.done(), k, __ATOMIC_RELEASE);  // (what the missing store would have written)
         p->rollback_launch();
-        return PIPE_HIP_EHIP;
+        R.state.store(pipe_hip_processor::Resident::kIdle, std::memory_order_release);
+        return rc != PIPE_HIP_OK ? rc : PIPE_HIP_EHIP;
     }
-    return rc;
+    return PIPE_HIP_OK;
 }
-// run what is queued on whatever the staging buffer holds, and take it back (resident.mu held)
+// Take back what is queued (resident.mu held): ring if nobody has, wait for the stale run, point the state back.
 int resident_cancel_locked(pipe_hip_processor *p)
 {
     pipe_hip_processor::Resident &R = p->resident;
-    if (!R.pending.load(std::memory_order_acquire))
+    using RS = pipe_hip_processor::Resident;
+    int st = R.state.load(std::memory_order_acquire);
+    if (st == RS::kIdle)
         return PIPE_HIP_OK;
-    __atomic_store_n(R.bell(), R.seq, __ATOMIC_RELEASE);
-    R.pending.store(false, std::memory_order_release);
-    PH_TRY(resident_wait(p, R.seq));
+    if (st == RS::kArmed) {
+        __atomic_store_n(R.bell(), R.seq, __ATOMIC_RELEASE);
+        R.dropped_by_entry.fetch_add(1, std::memory_order_relaxed);
+    }
+    const int rc = resident_wait(p, R.seq);
+    R.state.store(RS::kIdle, std::memory_order_release);
+    PH_TRY(rc);
     p->rollback_launch();
     return PIPE_HIP_OK;
 }
@@ -475,63 +526,145 @@ int resident_cancel(pipe_hip_processor *p)
     if (!p->resident.mail.p)
         return PIPE_HIP_OK;
     std::lock_guard<std::mutex> lk(p->resident.mu);
-    return resident_cancel_locked(p);
+    PH_TRY(resident_cancel_locked(p));
+    // (nothing of this handle is parked now, and it is the only handle of its device that ever parks anything: what
+    // it replaced while it queued work can be freed without waiting for a doorbell)
+    for (const DeferredFree &f : p->resident.frees)
+        (void)(f.pinned ? hipHostFree(f.p) : hipFree(f.p));
+    p->resident.frees.clear();
+    return PIPE_HIP_OK;
 }
-// before a device-wide synchronisation of our own: nothing of ours may be waiting for a doorbell on that device
-void resident_cancel_device(int device)
+// A foreign thread's part: ring, mark stale, leave (g_door_mu held).  Never waits; skips a handle whose owner is busy
+// with it (the owner rings its own doorbells).
+void resident_ring_foreign(pipe_hip_processor *p, bool by_watchdog, bool only_if_idle_too_long)
 {
-    std::lock_guard<std::mutex> lk(g_resident_mu);
-    for (pipe_hip_processor *p : g_resident)
-        if (p->cfg.device == device)
-            (void)resident_cancel(p);
+    pipe_hip_processor::Resident &R = p->resident;
+    using RS = pipe_hip_processor::Resident;
+    if (R.state.load(std::memory_order_acquire) != RS::kArmed)
+        return;
+    std::unique_lock<std::mutex> hl(R.mu, std::try_to_lock);
+    if (!hl.owns_lock() || R.state.load(std::memory_order_acquire) != RS::kArmed)
+        return;
+    if (only_if_idle_too_long && std::chrono::steady_clock::now() - R.armed_at < std::chrono::milliseconds(R.idle_ms))
+        return;
+    __atomic_store_n(R.bell(), R.seq, __ATOMIC_RELEASE);
+    R.state.store(RS::kStale, std::memory_order_release);
+    (by_watchdog ? R.dropped_by_watchdog : R.dropped_by_entry).fetch_add(1, std::memory_order_relaxed);
 }
-void resident_ring_all()
+// before a device-wide wait of our own (hipFree, hipDeviceSynchronize): nothing of ours should be parked on that
+// device.  `self`: the calling handle (its own queued work has been taken back by enter() already).
+void resident_ring_device(int device, const pipe_hip_processor *self)
 {
-    std::lock_guard<std::mutex> lk(g_resident_mu);
-    for (pipe_hip_processor *p : g_resident)
-        if (p->resident.pending.load() && p->resident.mail.p)
-            __atomic_store_n(p->resident.bell(), p->resident.seq, __ATOMIC_RELEASE);
+    if (device < 0 || device >= kMaxDevices)
+        return;
+    std::lock_guard<std::mutex> lk(g_door_mu);
+    pipe_hip_processor *o = g_door[device].owner;
+    if (o && o != self)
+        resident_ring_foreign(o, false, false);
+}
+void resident_ring_all()  // process exit: no queue may be left waiting for a host that has gone
+{
+    std::lock_guard<std::mutex> lk(g_door_mu);
+    for (int d = 0; d < kMaxDevices; ++d)
+        if (pipe_hip_processor *o = g_door[d].owner)
+            if (o->resident.mail.p && o->resident.state.load() == pipe_hip_processor::Resident::kArmed)
+                __atomic_store_n(o->resident.bell(), o->resident.seq, __ATOMIC_RELEASE);
 }
 void resident_watchdog()
 {
     for (;;) {
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
-        std::lock_guard<std::mutex> lk(g_resident_mu);
-        const auto now = std::chrono::steady_clock::now();
-        for (pipe_hip_processor *p : g_resident) {
-            pipe_hip_processor::Resident &R = p->resident;
-            if (!R.pending.load(std::memory_order_acquire))
-                continue;
-            std::unique_lock<std::mutex> hl(R.mu, std::try_to_lock);
-            if (!hl.owns_lock() || !R.pending.load() || now - R.armed_at < std::chrono::milliseconds(R.idle_ms))
-                continue;
-            if (hipSetDevice(p->cfg.device) == hipSuccess)
-                (void)resident_cancel_locked(p);
-            else
-                (void)hipGetLastError();
-        }
+        std::lock_guard<std::mutex> lk(g_door_mu);
+        for (int d = 0; d < kMaxDevices; ++d)
+            if (pipe_hip_processor *o = g_door[d].owner)
+                resident_ring_foreign(o, true, true);
     }
 }
-void resident_register(pipe_hip_processor *p)
+// the device's doorbell for `p` (its device selected): PIPE_HIP_EBUSY when another handle holds it
+int resident_acquire(pipe_hip_processor *p)
 {
-    std::lock_guard<std::mutex> lk(g_resident_mu);
+    const int d = p->cfg.device;
+    if (d < 0 || d >= kMaxDevices)
+        return PIPE_HIP_EINVAL;
+    std::lock_guard<std::mutex> lk(g_door_mu);
+    if (g_door[d].owner == p)
+        return PIPE_HIP_OK;
+    if (g_door[d].owner)
+        return PIPE_HIP_EBUSY;
     static bool hooked = false;
     if (!hooked) {
         hooked = true;
         std::atexit(resident_ring_all);
         std::thread(resident_watchdog).detach();
     }
-    g_resident.push_back(p);
-}
-void resident_unregister(pipe_hip_processor *p)
-{
-    std::lock_guard<std::mutex> lk(g_resident_mu);
-    for (size_t i = 0; i < g_resident.size(); ++i)
-        if (g_resident[i] == p) {
-            g_resident[i] = g_resident.back();
-            g_resident.pop_back();
-            break;
+    if (!g_door[d].stream) {
+        // a stream with every CU enabled in its mask: the runtime gives it a hardware queue of its own instead of one of
+        // the four that all other streams share (nothing is parked on this device now: no owner)
+        hipDeviceProp_t prop;
+        PH_HIP(hipGetDeviceProperties(&prop, d));
+        const int cus = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xFFFFFFFFu);
+        if (cus % 32)
+            mask.back() = (1u << (cus % 32)) - 1u;
+        hipStream_t s = nullptr;
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            return PIPE_HIP_EINVAL;  // (no such stream here: the handle stays on the plain path)
         }
+        g_door[d].stream = s;
+    }
+    g_door[d].owner = p;
+    return PIPE_HIP_OK;
+}
+void resident_release(pipe_hip_processor *p)
+{
+    const int d = p->cfg.device;
+    if (d < 0 || d >= kMaxDevices)
+        return;
+    std::lock_guard<std::mutex> lk(g_door_mu);
+    if (g_door[d].owner == p)
+        g_door[d].owner = nullptr;
+}
+hipStream_t resident_stream(int device) { return g_door[device].stream; }
+
+// switch the doorbell path of `p` on / off (its entry has run: nothing of its own is queued)
+int resident_enable(pipe_hip_processor *p, double value)
+{
+    pipe_hip_processor::Resident &R = p->resident;
+    if (value == 0.0) {
+        if (R.enabled) {
+            R.enabled = false;
+            (void)hipStreamSynchronize(p->stream);
+            if (R.own_stream) {
+                p->stream = R.own_stream;
+                R.own_stream = nullptr;
+            }
+            resident_release(p);
+        }
+        return PIPE_HIP_OK;
+    }
+    // one Line, a fixed-rate single-input stage that can take a queued launch back, buffers small enough
+    // for the zero-copy staging path
+    const size_t bytes = dtype_size(p->cfg.dtype) * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels * (size_t)p->cfg.lines;
+    if (p->owned_by_chain || !p->armable() || !p->fixed_rate() || !p->single_input() || bytes > ((size_t)1 << 20) || p->in_flight)
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->ensure_staging(0));
+    if (!p->stg[0].hd_in || !p->stg[0].hd_out)
+        return PIPE_HIP_EINVAL;
+    if (!R.mail.p) {
+        PH_TRY(R.mail.alloc(128, true));
+        std::memset(R.mail.p, 0, 128);
+    }
+    R.idle_ms = value > 1.0 ? (int)value : 250;  // (a value above 1: the idle limit in milliseconds)
+    if (R.enabled)
+        return PIPE_HIP_OK;
+    PH_TRY(resident_acquire(p));  // PIPE_HIP_EBUSY: another handle of this device holds the doorbell
+    PH_HIP(hipStreamSynchronize(p->stream));  // (the two streams trade places with nothing in flight on either)
+    R.own_stream = p->stream;
+    p->stream = resident_stream(p->cfg.device);
+    R.failed = false;
+    R.enabled = true;
+    return PIPE_HIP_OK;
 }
 }  // namespace
 
@@ -546,9 +679,14 @@ pipe_hip_processor::~pipe_hip_processor()
     if (cfg.buffer_size > 0)
         (void)hipSetDevice(cfg.device);
     if (resident.mail.p) {
-        resident_unregister(this);  // (first: the watchdog then no longer sees the handle)
         (void)resident_cancel(this);
+        if (resident.enabled)
+            (void)resident_enable(this, 0.0);  // (the handle's own stream back in `stream`, the doorbell free again)
     }
+    // (the frees below wait for every queue of the device: another handle's queued work is rung first, as a mutation
+    // of that handle would -- it runs on stale input and is taken back by its owner)
+    if (cfg.buffer_size > 0)
+        resident_ring_device(cfg.device, this);
     delete overlap;
     if (stream) {
         (void)hipStreamSynchronize(stream);
@@ -626,6 +764,25 @@ int finish_create(int rc, pipe_hip_processor **out)
     return rc;
 }
 
+// completion words instead of events for this handle's small calls?  (decided once per handle)
+bool express_on(pipe_hip_processor *p)
+{
+    if (p->express >= 0)
+        return p->express != 0;
+    p->express = 0;
+    static const bool by_event = std::getenv("PIPE_HIP_COMPLETION_EVENT") != nullptr;
+    int can = 0;
+    if (by_event || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, p->cfg.device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (p->express_mail.alloc(128, true) != PIPE_HIP_OK)
+        return false;
+    std::memset(p->express_mail.p, 0, 128);
+    p->express = 1;
+    return true;
+}
+
 // stage `in` and queue H2D -> stage body -> D2H on the handle's stream.  Up to two buffers may be
 // in flight: the second one's staging and launch overlap the first one's kernels and transfers.
 int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_t out_cap_hint)
@@ -663,12 +820,26 @@ int submit_impl(pipe_hip_processor *p, const void *in, int32_t in_frames, int32_
     if (in_b)
         std::memcpy(g.h_in.p, in, in_b);
     bool recorded = false;  // the stage's last launch carries g.done as its stop event
+    // Small calls complete by a WORD: hipStreamWriteValue32 behind the last launch, collect spins on it -- launch +
+    // word + spin 10.4 us against 13.0 us for launch + event (scripts/micro/queue_independence.hip); nothing waits in
+    // any queue, so any number of handles may do it.  Large calls (DMA path: milliseconds) keep the event.
+    g.express = zero_copy && express_on(p);
     if (zero_copy) {
-        p->completion = g.done;
+        p->completion = g.express ? nullptr : g.done;
         const int rc = p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, cap, &out_frames, p->stream);
-        recorded = p->completion == nullptr;
+        recorded = !g.express && p->completion == nullptr;
         p->completion = nullptr;
         PH_TRY(rc);
+        if (g.express) {
+            const unsigned t = ++p->express_ticket[slot];
+            if (hipStreamWriteValue32(p->stream, static_cast<unsigned *>(p->express_mail.p) + 16 * slot, t, 0) != hipSuccess) {
+                (void)hipGetLastError();  // (no stream memory operations after all: events from now on)
+                p->express = 0;
+                g.express = false;
+            } else {
+                recorded = true;
+            }
+        }
     } else {
         if (in_b)
             PH_HIP(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_b, hipMemcpyHostToDevice, p->stream));
@@ -693,8 +864,19 @@ int collect_impl(pipe_hip_processor *p, void *out, int32_t out_cap_frames, int32
     if (p->in_flight < 1)
         return PIPE_HIP_ESTATE;
     PH_TRY(p->enter());
-    pipe_hip_processor::Staging &g = p->stg[(p->submit_slot - p->in_flight) & 1];
-    PH_HIP(hipEventSynchronize(g.done));
+    const int slot = (p->submit_slot - p->in_flight) & 1;
+    pipe_hip_processor::Staging &g = p->stg[slot];
+    if (g.express) {
+        const unsigned *w = static_cast<const unsigned *>(p->express_mail.p) + 16 * slot;
+        if (!wait_word(w, p->express_ticket[slot], std::chrono::milliseconds(30000))) {
+            // half a minute: a device busy with somebody else's work, or gone -- the runtime's own wait ends either way
+            PH_HIP(hipStreamSynchronize(p->stream));
+            if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != p->express_ticket[slot])
+                return PIPE_HIP_EHIP;
+        }
+    } else {
+        PH_HIP(hipEventSynchronize(g.done));
+    }
     p->in_flight -= 1;
     // a look-back launch that gave up: with this buffer the only one in flight the call is run again here (with a
     // second one queued behind it -- submit / collect -- its work has already run on the failed one's state: reported)
@@ -851,6 +1033,7 @@ const char *pipe_hip_strerror(int status)
     case PIPE_HIP_ENOMEM: return "out of memory";
     case PIPE_HIP_ECAP: return "output exceeds buffer capacity";
     case PIPE_HIP_ESTATE: return "call out of order";
+    case PIPE_HIP_EBUSY: return "the device's doorbell is held by another handle";
     default: return "unknown status";
     }
 }
@@ -939,6 +1122,7 @@ int pipe_hip_start(pipe_hip_processor *p)
     PH_TRY(p->enter());
     PH_TRY(p->drain());  // a restarted pipe drops whatever was in flight, on whichever stream
     p->in_flight = 0;
+    p->resident.failed = false;
     PH_TRY(p->start(p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
     return PIPE_HIP_OK;
@@ -973,9 +1157,9 @@ int pipe_hip_destroy(pipe_hip_processor *p)
         return PIPE_HIP_OK;
     if (p->owned_by_chain)
         return PIPE_HIP_EINVAL;
-    (void)hipSetDevice(p->cfg.device);
-    resident_cancel_device(p->cfg.device);  // (no queue of ours may wait for a doorbell across the device-wide wait)
-    (void)hipDeviceSynchronize();
+    (void)p->enter();   // (its device; its own queued work taken back BEFORE any member is freed: a free waits for every queue)
+    (void)p->drain();   // everything the handle has queued anywhere (its own stream, a caller's stream of a batch call)
+    resident_ring_device(p->cfg.device, p);  // (another handle's queued work would hold the frees up until its watchdog)
     delete p;
     return PIPE_HIP_OK;
 }
@@ -1001,6 +1185,8 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         return PIPE_HIP_EINVAL;
     if (p->in_flight)  // collect would hand back an older buffer
         return PIPE_HIP_ESTATE;
+    if (p->resident.failed)  // a queued launch failed on the device: the state is unknown until the next StartFunc
+        return PIPE_HIP_ESTATE;
     // many Lines in one call: chunks of Lines, transfers and kernels overlapped
     if (p->fixed_rate() && p->single_input() && p->cfg.lines >= 2 && in && out && in_frames > 0 &&
         in_frames <= p->cfg.buffer_size && in_frames <= out_cap_frames) {
@@ -1023,18 +1209,20 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
     // (a stage whose form depends on the call's size -- the biquad: the tile form can be taken back, the ordered
     // recurrence cannot -- says per call whether its launch may be queued ahead; if not, the plain path below)
     if (p->resident.enabled && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
-        in_frames <= out_cap_frames && p->armable_for(in_frames, p->cfg.dtype)) {
+        in_frames <= out_cap_frames && !p->resident.failed && p->armable_for(in_frames, p->cfg.dtype)) {
         // The buffer's work is already on the device, behind the doorbell (queued while the last buffer ran):
         // copy in, ring, queue the NEXT buffer's work while this one runs, spin on the completion word.
         pipe_hip_processor::Resident &R = p->resident;
+        using RS = pipe_hip_processor::Resident;
         PH_TRY(p->select_device());
-        std::lock_guard<std::mutex> lk(R.mu);  // (the watchdog keeps its hands off until the result is out)
-        if (R.pending.load() && R.frames != in_frames)
-            PH_TRY(resident_cancel_locked(p));  // (a short buffer: pipe.go:441-443)
-        if (!R.pending.load()) {  // the first call, or the one after a cancellation
+        std::unique_lock<std::mutex> lk(R.mu);  // (the watchdog keeps its hands off until the result is out)
+        if (R.state.load() == RS::kStale || (R.state.load() == RS::kArmed && R.frames != in_frames))
+            PH_TRY(resident_cancel_locked(p));  // (rung by somebody else meanwhile / a short buffer: pipe.go:441-443)
+        if (R.state.load() == RS::kIdle) {  // the first call, or the one after a cancellation
             const int rc0 = resident_arm(p, in_frames);
             if (rc0 == kResidentUnsupported) {  // no stream memory operations here: the plain path from now on
-                R.enabled = false;
+                lk.unlock();
+                (void)resident_enable(p, 0.0);
                 goto plain_path;
             }
             PH_TRY(rc0);
@@ -1045,18 +1233,24 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         const unsigned k = R.seq;
         const int64_t produced = R.out_frames;
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
-        R.pending.store(false);
+        R.state.store(RS::kIdle, std::memory_order_release);  // (rung by its own call: running, nothing parked)
         int rc_next = resident_arm(p, in_frames);
-        if (rc_next == kResidentUnsupported) {  // (it worked a call ago: treat as a runtime error of this call's successor)
-            R.enabled = false;
-            rc_next = PIPE_HIP_OK;
-        }
+        if (rc_next == kResidentUnsupported)  // (it worked a call ago: a runtime error of this call's successor)
+            rc_next = PIPE_HIP_EHIP;
         PH_TRY(resident_wait(p, k));
+        if (p->take_failure_flag()) {
+            // Launch k failed on the device (a look-back that gave up) and launch k + 1 is queued on its state: neither
+            // can be taken back any more.  Drop what is queued and say so -- a ProcessFunc error ends the run
+            // (pipe.go:438-440); the next StartFunc begins from silence.
+            (void)resident_cancel_locked(p);
+            (void)p->take_failure_flag();
+            R.failed = true;
+            return PIPE_HIP_EHIP;
+        }
         std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
         if (out_frames)
             *out_frames = (int32_t)produced;
-        PH_TRY(rc_next);
-        return p->poll_error();
+        return rc_next;
     }
 plain_path:
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
@@ -1395,27 +1589,7 @@ int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *value
     if (param == PIPE_HIP_PARAM_RESIDENT) {
         if (count != 1)
             return PIPE_HIP_EINVAL;
-        pipe_hip_processor::Resident &R = p->resident;
-        if (values[0] == 0.0) {
-            R.enabled = false;  // (enter() has run what was queued)
-            return PIPE_HIP_OK;
-        }
-        // one Line, a fixed-rate single-input stage that can take a queued launch back, buffers small enough
-        // for the zero-copy staging path
-        const size_t bytes = dtype_size(p->cfg.dtype) * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels * (size_t)p->cfg.lines;
-        if (p->owned_by_chain || !p->armable() || !p->fixed_rate() || !p->single_input() || bytes > ((size_t)1 << 20) || p->in_flight)
-            return PIPE_HIP_EINVAL;
-        PH_TRY(p->ensure_staging(0));
-        if (!p->stg[0].hd_in || !p->stg[0].hd_out)
-            return PIPE_HIP_EINVAL;
-        if (!R.mail.p) {
-            PH_TRY(R.mail.alloc(128, true));
-            std::memset(R.mail.p, 0, 128);
-            resident_register(p);
-        }
-        R.enabled = true;
-        R.idle_ms = values[0] > 1.0 ? (int)values[0] : 250;  // (a value above 1: the idle limit in milliseconds)
-        return PIPE_HIP_OK;
+        return resident_enable(p, values[0]);  // (enter() has taken back what was queued)
     }
     return p->set_param(param, values, count);
 }
@@ -1486,6 +1660,20 @@ int pipe_hip_kernel_time(pipe_hip_processor *p, double *total_ms, int64_t *launc
 }
 
 const char *pipe_hip_kernel_name(const pipe_hip_processor *p) { return p ? p->last_kernel : ""; }
+
+int pipe_hip_resident_info(pipe_hip_processor *p, int32_t *holds_doorbell, int64_t *dropped_by_watchdog,
+                           int64_t *dropped_by_entry)
+{
+    if (!p)
+        return PIPE_HIP_EINVAL;
+    if (holds_doorbell)
+        *holds_doorbell = p->resident.enabled ? 1 : 0;
+    if (dropped_by_watchdog)
+        *dropped_by_watchdog = p->resident.dropped_by_watchdog.load();
+    if (dropped_by_entry)
+        *dropped_by_entry = p->resident.dropped_by_entry.load();
+    return PIPE_HIP_OK;
+}
 
 int pipe_hip_host_alloc(int64_t bytes, void **ptr)
 {

@@ -1341,6 +1341,21 @@ public:
         *e = 0;
         return true;
     }
+    // (the queued-ahead path: launch k's flag while launch k + 1 is queued -- the flag only, err_checked_ describes k + 1)
+    bool take_failure_flag() override
+    {
+        bool f = false;
+        for (auto &h : half_)
+            f = (h && h->take_failure_flag()) || f;
+        if (err_.p) {
+            volatile int *e = static_cast<volatile int *>(err_.p);
+            if (*e != 0) {
+                *e = 0;
+                f = true;
+            }
+        }
+        return f;
+    }
     int settle(hipStream_t s, bool *reran) override
     {
         if (reran)

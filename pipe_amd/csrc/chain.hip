@@ -53,7 +53,7 @@ public:
         // FIR -> biquad (-> gain) on float32 buffers, a call large enough for the overlap-save
         // form: ONE kernel, one read and one write of the buffers (chain_fused.hip)
         last_fused_.valid = false;
-        if (!no_fuse_ && fusable(d_in, in_dtype, d_out, out_dtype, frames)) {
+        if (!no_fuse_ && !queued_run && fusable(d_in, in_dtype, d_out, out_dtype, frames)) {
             FirFuseView fv{};
             BiquadFuseView bv{};
             double g = 1.0;
@@ -94,6 +94,7 @@ public:
             // float64 intermediates of a chain that ends in float32 may take the FIR's
             // overlap-save form: its O(1e-16) perturbation stays far below the final ulp
             stages[i]->relaxed_f64_out = !last && out_dtype == PIPE_HIP_F32;
+            stages[i]->queued_run = queued_run;
             if (last) {  // the buffer's completion event may ride on the last stage's last launch
                 stages[i]->completion = completion;
                 completion = nullptr;
@@ -115,8 +116,16 @@ public:
         last_kernel = stages.empty() ? "" : stages[0]->last_kernel;
         return PIPE_HIP_OK;
     }
-    // PIPE_HIP_PARAM_RESIDENT: a chain of stages each of which can take a queued launch back (FIR, gain); per-buffer
-    // calls never take the fused kernel, whose state lives in tagged slots
+    // PIPE_HIP_PARAM_RESIDENT: a chain of stages each of which can take a queued launch back (FIR, gain, the tile
+    // biquad); a run that is queued ahead (queued_run) never takes the fused kernel, whose state lives in tagged
+    // slots that rollback_launch() does not reach and whose plan may allocate and synchronise on the way
+    bool take_failure_flag() override
+    {
+        bool f = false;
+        for (auto &st : stages)
+            f = st->take_failure_flag() || f;
+        return f;
+    }
     bool armable() const override
     {
         for (auto &st : stages)
@@ -176,12 +185,12 @@ public:
             *reran = false;
         if (!fused_ || !last_fused_.valid) {
             int rc = fused_ ? fused_->poll_error() : PIPE_HIP_OK;
-            for (auto &st : stages) {  // (the staged chain: a stage that ran a look-back form looks after itself --
-                bool again = false;    //  its input, the chain's float64 intermediate, is still there; what it rewrote
-                const int r = st->settle(s, &again);  // feeds the stages behind it, so they run again too)
+            for (size_t i = 0; i < stages.size(); ++i) {  // (the staged chain: a stage that ran a look-back form looks
+                bool again = false;  // after itself -- its input, the chain's float64 intermediate, is still there)
+                const int r = stages[i]->settle(s, &again);
                 rc = rc != PIPE_HIP_OK ? rc : r;
                 if (again && rc == PIPE_HIP_OK) {
-                    rc = rerun_staged(s);
+                    rc = rerun_staged(s, i);
                     if (reran)
                         *reran = true;
                     break;
@@ -252,15 +261,20 @@ private:
     };
     FusedCall last_fused_{nullptr, nullptr, 0, 0, 0, false}, last_staged_{nullptr, nullptr, 0, 0, 0, false};
     bool no_fuse_ = false;
-    // A stage of the staged chain ran its call again (its state is right again): the stages behind it have consumed
-    // what it wrote before.  Stages BEFORE it have advanced once and must not advance twice, so only the tail runs:
-    // simplest is to note that every stage but look-back ones is deterministic in (state, input) -- the rerun
-    // stage wrote the same buffer the next stage reads, so running the stages behind it again needs THEIR state
-    // of before the call, which only look-back stages keep.  A chain is FIR -> biquad (-> gain): behind the biquad
-    // sits at most a stateless gain, folded into the biquad's own store.  Nothing to do but wait.
-    int rerun_staged(hipStream_t s)
+    // A stage of the staged chain ran its call again (its state is right again, and it rewrote the buffer the next
+    // stage reads).  The stages BEHIND it have consumed what it wrote before and advanced on it; running them again
+    // needs their state of before the call, which only look-back stages keep.  So: fine when nothing with state
+    // sits behind the stage that ran again (FIR -> biquad (-> gain): a gain is stateless and folded into the biquad's
+    // own store); any other order (biquad -> FIR, biquad -> biquad) has consumed wrong samples -- reported, loudly,
+    // as the device failure it is (pipe.go:438-440: a ProcessFunc error ends the run).
+    int rerun_staged(hipStream_t s, size_t stage)
     {
         PH_HIP(hipStreamSynchronize(s));
+        for (size_t j = stage + 1; j < stages.size(); ++j) {
+            double g;
+            if (!gain_value(stages[j].get(), &g))
+                return PIPE_HIP_EHIP;
+        }
         return PIPE_HIP_OK;
     }
     // the state of before the failed launch: the cascade's from the slot the launch did not write, the FIR's

@@ -39,6 +39,17 @@ extern thread_local int g_last_hip_error;
 
 inline size_t dtype_size(int dtype) { return dtype == PIPE_HIP_F64 ? 8 : 4; }
 
+// hipFree / hipHostFree wait for EVERY queue of the device -- also for one that is parked behind a doorbell only the
+// calling thread can ring (PIPE_HIP_PARAM_RESIDENT: the work of the next buffer is queued while the handle's lock is
+// held).  While a thread queues such work, g_deferred_frees points at its handle's list: a buffer that grows then
+// leaves its old allocation on the list instead of freeing it, and the handle frees the list at its next ordinary
+// entry, when nothing of its own is parked (abi.hip: pipe_hip_processor::enter).
+struct DeferredFree {
+    void *p;
+    bool pinned;
+};
+extern thread_local std::vector<DeferredFree> *g_deferred_frees;
+
 // Device allocation owned by a handle.
 struct DevBuf {
     void *p = nullptr;
@@ -54,7 +65,9 @@ struct DevBuf {
     }
     void release()
     {
-        if (p)
+        if (p && g_deferred_frees)
+            g_deferred_frees->push_back(DeferredFree{p, false});
+        else if (p)
             (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -82,7 +95,9 @@ struct PinnedBuf {
     }
     void release()
     {
-        if (p)
+        if (p && g_deferred_frees)
+            g_deferred_frees->push_back(DeferredFree{p, true});
+        else if (p)
             (void)hipHostFree(p);
         p = nullptr;
         bytes = 0;
@@ -212,6 +227,7 @@ struct pipe_hip_processor {
         hipEvent_t done = nullptr;
         int32_t out_frames = 0;
         bool zero_copy = false;  // the kernels read / wrote the pinned buffers themselves (no D2H copy to redo after a rerun)
+        bool express = false;    // the call completes by a word in pinned memory (express_mail), not by `done`
     };
     Staging stg[2];
     // Set by submit while it queues a buffer: a stage whose LAST device operation for the call is a
@@ -352,26 +368,51 @@ struct pipe_hip_processor {
     // whether the launch can be taken back -- depends on the call's size)
     virtual bool armable_for(int64_t /*frames*/, int /*out_dtype*/) { return armable(); }
     virtual void rollback_launch() {}
+    // set around the run() that is queued behind a doorbell: forms that may synchronise, allocate on the way or keep
+    // state a rollback_launch() cannot take back (the fused chain kernel) are not chosen for it
+    bool queued_run = false;
+    // the device-side failure flag of the stage's look-back forms, read and cleared, NOTHING else touched (the
+    // queued-ahead path looks at launch k's flag when launch k + 1 is already queued: settle() / poll_error()
+    // would take back the wrong launch)
+    virtual bool take_failure_flag() { return false; }
     struct Resident {
-        bool enabled = false;
+        // What the measurements allow (scripts/micro/queue_independence.hip): a queue that waits for a
+        // doorbell holds up whatever shares its hardware queue, and every OTHER parked queue of the process costs
+        // the one that is rung tens of microseconds.  So at most ONE handle per device holds the doorbell, and its
+        // work goes to a stream with a hardware queue of its own (one per device, made once, never destroyed).
+        bool enabled = false;         // this handle holds its device's doorbell
         pipehip::PinnedBuf mail;      // doorbell word at +0, completion word at +64 (coherent pinned memory)
         unsigned seq = 0;             // the sequence number the queued work waits for
-        std::atomic<bool> pending{false};  // work is queued behind `seq`
+        // idle: nothing queued.  armed: the work of the next buffer waits for doorbell `seq`.  stale: somebody
+        // other than the next call rang it (the watchdog, another handle's destruction, this handle's own entries):
+        // the work runs on whatever the staging buffer holds; before the handle does anything else it waits for the
+        // completion word and takes the launch back.
+        enum State : int { kIdle = 0, kArmed = 1, kStale = 2 };
+        std::atomic<int> state{kIdle};
         int32_t frames = 0;           // ... for a buffer of this many frames
         int64_t out_frames = 0;
-        // A queue that waits for a doorbell also holds up every device-wide synchronisation of the process
-        // (hipDeviceSynchronize: torch.cuda.synchronize(), a handle's destruction).  So queued work does not
-        // outlive `idle_ms` without a call: a watchdog thread of the library then runs it on stale input and takes
-        // it back, exactly as a mutation would (the next call queues afresh).  `mu` is held by whoever touches
-        // the doorbell, the queued work or the staging buffers: the fast path for its whole length, the
-        // watchdog, every other entry while it cancels.
+        // `mu` is held by whoever touches the doorbell, the queued work or the staging buffers: the fast path for
+        // its whole length, every other entry while it takes queued work back.  Foreign threads (the watchdog,
+        // another handle that is about to wait for the whole device) only ever TRY it, ring, mark the work stale and
+        // leave: nobody waits for the device while holding a lock that somebody else needs to ring a doorbell.
         std::mutex mu;
         std::chrono::steady_clock::time_point armed_at{};
         int idle_ms = 250;
+        std::atomic<int64_t> dropped_by_watchdog{0};  // queued launches run on stale input and dropped: rung by the watchdog
+        std::atomic<int64_t> dropped_by_entry{0};     // ... by another entry (a mutation, a short buffer, start, flush, destroy)
+        std::vector<pipehip::DeferredFree> frees;     // allocations replaced while work was being queued (freed at the next entry)
+        hipStream_t own_stream = nullptr;             // the handle's ordinary stream while `stream` is the device's doorbell stream
+        bool failed = false;          // a queued launch failed on the device: the state is unknown until the next StartFunc
         unsigned *bell() const { return static_cast<unsigned *>(mail.p); }
         unsigned *done() const { return static_cast<unsigned *>(mail.p) + 16; }
     };
     Resident resident;
+    // ---- completion of a per-buffer call by a word in pinned memory (abi.hip: express completion) ----
+    // hipStreamWriteValue32 behind the call's last launch, the host spins on the word: 2.6 us less per call than an
+    // event (scripts/micro/queue_independence.hip), nothing parked anywhere.  Per staging slot: word at +0 / +64.
+    pipehip::PinnedBuf express_mail;
+    unsigned express_ticket[2] = {0, 0};
+    int express = -1;  // -1: not decided yet, 0: events (PIPE_HIP_COMPLETION_EVENT, or the device cannot), 1: completion words
 
     int init_common(const pipe_hip_config *c);
     int ensure_staging(int slot = 0);

@@ -565,6 +565,7 @@ public:
     int run(const void *d_in, int in_dtype, void *d_out, int out_dtype, int64_t frames,
             hipStream_t s) override
     {
+        last_flipped_ = false;
         if (frames <= 0)
             return PIPE_HIP_OK;
         PH_TRY(order_after_upload(s));
@@ -578,7 +579,8 @@ public:
         // Large float32 batches take the overlap-save FFT form (<= 1 ulp f32 of the
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
-        if (ols_ && !exact_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
+        // (a run that is queued behind a doorbell keeps to the direct form: nothing in it allocates or synchronises)
+        if (ols_ && !exact_ && !queued_run && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
             ols_->items(frames, cfg.channels, nl) >= ols_min_items() &&
             (!ols_->partitioned() || (reinterpret_cast<uintptr_t>(d_in) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(in_dtype)) == 0 &&
                                        reinterpret_cast<uintptr_t>(d_out) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(out_dtype)) == 0))) {
@@ -589,7 +591,7 @@ public:
         const double *taps = static_cast<const double *>(taps_[cur_taps_].p);
         // the ordered-fma form: large calls on the float64 matrix pipe (fir_mfma.hip: the same chain
         // of fused multiply-adds, 1024 of them per instruction), the rest on the VALU
-        if (fir_mfma_takes(N_, frames, cfg.channels, nl, cus_, knobs.fir_mfma_min_passes)) {
+        if (!queued_run && fir_mfma_takes(N_, frames, cfg.channels, nl, cus_, knobs.fir_mfma_min_passes)) {
             hipEvent_t *done = windowed() ? nullptr : &completion;
             PH_TRY(run_fir_mfma(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, taps, N_, frames, cfg.channels, nl,
                                 cus_, s, &last_kernel, &timer, done));
@@ -627,11 +629,13 @@ public:
 
     // PIPE_HIP_PARAM_RESIDENT: a queued launch wrote the OTHER half of the history double buffer and
     // flip_history() pointed the stage at it; taking the launch back is pointing it at the old half again
+    // (only a run() that got as far as flip_history() has anything to take back: last_flipped_)
     bool armable() const override { return true; }
     void rollback_launch() override
     {
-        if (H_ > 0)
+        if (H_ > 0 && last_flipped_)
             cur_hist_ ^= 1;
+        last_flipped_ = false;
     }
 
     bool fuse_view_fir(FirFuseView *v, hipStream_t s, bool prepare) override
@@ -702,8 +706,10 @@ private:
             return PIPE_HIP_OK;
         }
         cur_hist_ ^= 1;
+        last_flipped_ = true;
         return PIPE_HIP_OK;
     }
+    bool last_flipped_ = false;  // the last run() flipped the history halves (rollback_launch flips them back)
 
     // tile geometry for register blocking R with the channels split `split` ways
     bool geometry(int R, int split, int64_t frames, Geometry *g) const

@@ -289,11 +289,23 @@ class Processor:
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         L.check(L.lib().pipe_hip_set_param(self._h, param, _dptr(v), v.size), "set_param")
 
-    def set_resident(self, on: bool = True):
+    def set_resident(self, on: bool = True, idle_ms: int = 0) -> bool:
         """PIPE_HIP_PARAM_RESIDENT: keep the next buffer's work queued on the device behind a doorbell, so that
         process() costs no kernel launch and no completion event (stages that can take a queued launch back:
-        gain, FIR, chains of those; one buffer of at most 1 MiB)."""
-        self._set_param(L.PARAM_RESIDENT, [1.0 if on else 0.0])
+        gain, FIR, the tile biquad, chains of those; one buffer of at most 1 MiB).  ONE handle per device can hold
+        the doorbell: False when another handle holds it (PIPE_HIP_EBUSY) -- this handle stays on the plain path."""
+        v = np.ascontiguousarray([float(idle_ms) if (on and idle_ms > 1) else (1.0 if on else 0.0)], dtype=np.float64)
+        st = L.lib().pipe_hip_set_param(self._h, L.PARAM_RESIDENT, _dptr(v), 1)
+        if st == L.EBUSY:
+            return False
+        L.check(st, "set_param(RESIDENT)")
+        return True
+
+    def resident_info(self):
+        """(holds the doorbell, queued launches dropped by the watchdog, ... dropped by another entry)"""
+        held, wd, en = C.c_int32(), C.c_int64(), C.c_int64()
+        L.check(L.lib().pipe_hip_resident_info(self._h, C.byref(held), C.byref(wd), C.byref(en)), "resident_info")
+        return bool(held.value), wd.value, en.value
 
 
 class Gain(Processor):

@@ -26,7 +26,7 @@ def test_fir_stream_is_the_oracles_bit_for_bit(dtype):
     with P.Fir(taps, F, C, dtype=dtype) as fir, P.Fir(taps, F, C, dtype=dtype) as plain:
         fir.start()
         plain.start()
-        fir.set_resident(True)
+        assert fir.set_resident(True)
         ref = O.Fir(taps, C)
         for k in range(12):
             frames = F if k != 7 and k != 11 else (1000 if k == 7 else 17)  # short buffers in the middle and at the end
@@ -44,7 +44,7 @@ def test_a_taps_mutation_reaches_the_next_buffer_and_no_other():
     x = stream(4, 8).astype(np.float32)
     with P.Fir(taps, F, C, dtype=np.float32) as fir:
         fir.start()
-        fir.set_resident(True)
+        assert fir.set_resident(True)
         ref = O.Fir(taps, C)
         for k in range(8):
             if k == 3:  # the queued launch of buffer 3 was made with the old taps: it is run and dropped
@@ -59,7 +59,7 @@ def test_gain_and_its_mutation():
     x = stream(5, 6).astype(np.float32)
     with P.Gain(0.25, F, C, dtype=np.float32) as g:
         g.start()
-        g.set_resident(True)
+        assert g.set_resident(True)
         for k in range(6):
             if k == 4:
                 g.set_gain(-3.0)
@@ -73,7 +73,7 @@ def test_chain_of_fir_and_gain_restart_and_other_entries():
     x = stream(6, 10).astype(np.float32)
     with P.Chain([P.Fir(taps, F, C, dtype=np.float32), P.Gain(0.5, F, C, dtype=np.float32)]) as ch:
         ch.start()
-        ch.set_resident(True)
+        assert ch.set_resident(True)
         ref = O.Fir(taps, C)
         for k in range(10):
             if k == 4:  # StartFunc in the middle: the queued launch is taken back, state is silence again
@@ -108,7 +108,7 @@ def test_a_biquad_is_queued_ahead_for_the_calls_that_take_its_tile_form():
         with mk(np.float32) as res, mk(np.float32) as plain:
             res.start()
             plain.start()
-            res.set_resident(True)
+            assert res.set_resident(True)
             for k in range(8):
                 frames = 300 if k == 3 else (2000 if k == 5 else F)   # (300: the ordered form; 2000: another tile call)
                 if k == 6:
@@ -119,7 +119,7 @@ def test_a_biquad_is_queued_ahead_for_the_calls_that_take_its_tile_form():
                 assert np.array_equal(res.process(xin), plain.process(xin)), k
         with mk(np.float64) as r64:
             r64.start()
-            r64.set_resident(True)
+            assert r64.set_resident(True)
             refs = [O.Biquad(q, C)] if not hasattr(r64, "stages") else [O.Fir(taps, C), O.Biquad(q, C)]
             for k in range(3):
                 y = x[k]
@@ -152,7 +152,7 @@ def test_a_handle_destroyed_with_work_queued_leaves_nothing_waiting():
     for _ in range(3):
         g = P.Gain(2.0, F, C, dtype=np.float32)
         g.start()
-        g.set_resident(True)
+        assert g.set_resident(True)
         assert np.array_equal(g.process(x[0]), (x[0] * 2.0).astype(np.float32))
         g.close()  # a launch for the next buffer is queued behind the doorbell right now
     with P.Gain(2.0, F, C, dtype=np.float32) as g2:  # the device still answers
@@ -181,3 +181,86 @@ def test_queued_work_does_not_hold_a_device_wide_synchronisation_for_ever():
                 assert time.perf_counter() - t0 < 2.0
             if k == 2:
                 time.sleep(0.2)  # the watchdog has taken the queued work back: the next call queues afresh
+
+
+
+def test_one_doorbell_per_device_and_the_second_handle_stays_on_the_plain_path():
+    """A queue that waits for a doorbell costs every other waiting queue of the process tens of microseconds
+    (scripts/micro/queue_independence.hip), so ONE handle per device holds the doorbell; the next one that asks is
+    answered PIPE_HIP_EBUSY and runs the plain path -- same bits -- until the holder gives it back."""
+    x = stream(11, 6).astype(np.float32)
+    with P.Gain(0.5, F, C, dtype=np.float32) as a, P.Gain(0.25, F, C, dtype=np.float32) as b:
+        a.start()
+        b.start()
+        assert a.set_resident(True) is True
+        assert a.set_resident(True) is True          # asking twice is fine
+        assert b.set_resident(True) is False         # PIPE_HIP_EBUSY
+        assert a.resident_info()[0] and not b.resident_info()[0]
+        for k in range(3):
+            assert np.array_equal(a.process(x[k]), (x[k] * 0.5).astype(np.float32))
+            assert np.array_equal(b.process(x[k]), (x[k] * 0.25).astype(np.float32))
+        assert a.set_resident(False) is True         # the doorbell is free again
+        assert b.set_resident(True) is True
+        for k in range(3, 6):
+            assert np.array_equal(a.process(x[k]), (x[k] * 0.5).astype(np.float32))
+            assert np.array_equal(b.process(x[k]), (x[k] * 0.25).astype(np.float32))
+    with P.Gain(2.0, F, C, dtype=np.float32) as c:   # ... and after its holder was destroyed
+        c.start()
+        assert c.set_resident(True) is True
+
+
+def test_dropped_launches_are_counted():
+    import time
+    x = stream(12, 4).astype(np.float32)
+    with P.Gain(0.5, F, C, dtype=np.float32) as g:
+        g.start()
+        assert g.set_resident(True, idle_ms=40)
+        g.process(x[0])
+        time.sleep(0.25)                              # no call for 40 ms: the watchdog rings, the work runs on stale input
+        held, by_watchdog, by_entry = g.resident_info()
+        assert held and by_watchdog == 1 and by_entry == 0
+        assert np.array_equal(g.process(x[1]), (x[1] * 0.5).astype(np.float32))
+        g.set_gain(2.0)                               # a mutation finds queued work: one more dropped launch
+        assert g.resident_info()[2] == 1
+        assert np.array_equal(g.process(x[2]), (x[2] * 2.0).astype(np.float32))
+
+
+def test_a_stage_that_grows_its_scratch_while_work_is_being_queued():
+    """The tile biquad sizes its look-back area by the call: 2000 frames first, then full buffers -- the larger area is
+    allocated while the wait for the next doorbell is already queued; the old one must not be freed there (a free
+    waits for every queue of the device, this one included: ADVICE r4)."""
+    q = synth.biquad_rbj_lowpass()
+    x = stream(13, 6).astype(np.float32)
+    with P.Biquad(q, 4 * F, C, dtype=np.float32) as res, P.Biquad(q, 4 * F, C, dtype=np.float32) as plain:
+        res.start()
+        plain.start()
+        assert res.set_resident(True)
+        big = np.concatenate([x[2], x[3], x[4], x[5]])
+        for xin in (x[0][:2000], x[1][:2000], x[1], big, big, x[0][:1024]):
+            assert np.array_equal(res.process(xin), plain.process(xin))
+
+
+def test_a_queued_launch_that_fails_on_the_device_ends_the_run_loudly():
+    """PIPE_HIP_PARAM_DEBUG makes the next tile launch give up on a predecessor tile.  On the plain path the call is
+    run again through the ordered recurrence; queued ahead, its successor is already queued on its state, so the call
+    answers PIPE_HIP_EHIP (pipe.go:438-440: a ProcessFunc error ends the run), further calls PIPE_HIP_ESTATE, and the
+    next StartFunc begins from silence -- bit for bit a fresh handle."""
+    q = synth.biquad_rbj_lowpass()
+    FB = 4 * F                                          # four tiles of 4096 frames a call: tile 1 has a predecessor
+    x = stream(14, 4, frames=FB).astype(np.float32)
+    with P.Biquad(q, FB, C, dtype=np.float32) as res, P.Biquad(q, FB, C, dtype=np.float32) as fresh:
+        res.start()
+        fresh.start()
+        assert res.set_resident(True)
+        res.process(x[0])
+        assert res.kernel_name().startswith("biquad_tile_kernel"), res.kernel_name()
+        res._set_param(L.PARAM_DEBUG, [1.0, 20000.0])   # (the queued launch is dropped; the next one will fail)
+        with pytest.raises(L.PipeHipError) as e:
+            res.process(x[1])
+        assert e.value.status == L.EHIP
+        with pytest.raises(L.PipeHipError) as e:
+            res.process(x[2])
+        assert e.value.status == L.ESTATE
+        res.start()
+        for k in range(4):
+            assert np.array_equal(res.process(x[k]), fresh.process(x[k])), k

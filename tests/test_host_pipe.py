@@ -194,17 +194,59 @@ def test_hip_processor_error_surfaces_as_run_error():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
-def test_the_host_loop_through_the_resident_path(mode, monkeypatch):
-    """run.go:198-224's loop with every stage that can take a queued launch back (gain, FIR) keeping its NEXT buffer's
-    work queued on the device behind a doorbell (PIPE_HIP_PARAM_RESIDENT; the harness's PIPE_HOST_RESIDENT is what
-    hip.Stage.SetResident is in the Go shim): the same known answers, the same bits as the plain path -- short last
-    buffers, restarts between runs, an in-band mutation, an error that ends the run."""
-    monkeypatch.setenv("PIPE_HOST_RESIDENT", "1")
-    test_hip_copy_in_the_loop_config1(mode)
-    test_hip_fir_biquad_gain_lines_equal_oracle_loop(mode)
-    test_hip_fused_chain_equals_separate_stages_and_oracle()
-    test_mutation_reaches_hip_handle_through_the_message()
-    test_hip_processor_error_surfaces_as_run_error()
+def test_the_host_loop_through_the_resident_path(mode):
+    """run.go:198-224's loop with PIPE_HIP_PARAM_RESIDENT asked for by EVERY HIP stage (the harness's
+    PIPE_HOST_RESIDENT is what hip.Stage.SetResident is in the Go shim): the first stage of the device that can take a
+    queued launch back holds the doorbell, the others are answered PIPE_HIP_EBUSY / EINVAL and stay on the plain
+    path -- the same known answers, the same bits as without it: short last buffers, restarts between runs, an
+    in-band mutation, an error that ends the run.  In a child process with a limit of its own (async mode: a thread
+    per component; this is the test that never returned in round 4)."""
+    from tests._child import run_child
+    run_child(f"""
+        import tests.test_host_pipe as T
+        T.test_hip_copy_in_the_loop_config1({mode})
+        T.test_hip_fir_biquad_gain_lines_equal_oracle_loop({mode})
+        T.test_hip_fused_chain_equals_separate_stages_and_oracle()
+        T.test_mutation_reaches_hip_handle_through_the_message()
+        T.test_hip_processor_error_surfaces_as_run_error()
+    """, timeout_s=90, env={"PIPE_HOST_RESIDENT": "1"})
+
+
+@pytest.mark.gpu
+def test_many_lines_of_resident_stages_async_stress():
+    """8 Lines x (FIR, gain), every stage asking for the doorbell, async mode (17+ threads), 2000 buffers a Line, 20
+    times over: every run equal to the oracle's loop and done within 10 s.  Components that run concurrently must not
+    hold each other up (merger.go:25-30, run.go:171-196, fitting.go:56-60): one stage holds the device's doorbell on a
+    hardware queue of its own, nobody else parks anything."""
+    from tests._child import run_child
+    out = run_child("""
+        import time
+        import numpy as np
+        from oracle import oracle as O
+        from pipe_amd import host as H
+        from pipe_amd import synth
+        BUF, LINES, BUFFERS, REPS = 512, 8, 2000, 20
+        taps = synth.fir_lowpass_taps(32)
+        n = BUFFERS * BUF - 77   # (a short last buffer)
+        mk = lambda i: dict(limit=n, channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False)
+        olines = [O.Line(limit=n, channels=2, src_kind=O.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                         procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_GAIN, [0.5])]) for i in range(LINES)]
+        oerr, ores = O.run_lines(BUF, olines)
+        worst = 0.0
+        for rep in range(REPS):
+            hlines = [H.Line(procs=[H.Proc(H.PROC_HIP_FIR, taps), H.Proc(H.PROC_HIP_GAIN, [0.5])], **mk(i)) for i in range(LINES)]
+            t0 = time.perf_counter()
+            herr, hres = H.run(BUF, hlines, H.MODE_ASYNC)
+            dt = time.perf_counter() - t0
+            worst = max(worst, dt)
+            assert not herr.failed, herr.message
+            assert dt < 10.0, (rep, dt)
+            for h, o in zip(hres, ores):
+                assert (h.sink.messages, h.sink.samples) == (o.sink.messages, o.sink.samples)
+                assert np.array_equal(h.values, o.values), rep
+        print(f"worst run {worst:.2f} s", flush=True)
+    """, timeout_s=280, env={"PIPE_HOST_RESIDENT": "1"})
+    assert "worst run" in out
 
 
 # ---------------------------------------------------------- stage-major (batched) Run
