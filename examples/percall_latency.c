@@ -1,8 +1,10 @@
 /*
  * What one ProcessFunc call costs through the C ABI (the cost a cgo shim adds is ~0.1 us on top): one
  * 4096 x 2 pipe buffer per pipe_hip_process, float32 and float64 buffers, for a gain, a 256-tap FIR and a
- * FIR -> gain chain -- on the plain path (launch + completion event per call) and with
- * PIPE_HIP_PARAM_RESIDENT (the next buffer's work queued on the device behind a doorbell).
+ * FIR -> gain chain, a biquad and FIR -> biquad -> gain (float64 buffers also with PIPE_HIP_PARAM_RELAXED_F64) -- on the
+ * plain path (launch + completion word per call; PIPE_HIP_COMPLETION_EVENT=1 in the environment: a completion event,
+ * round 4's plain path) and with PIPE_HIP_PARAM_RESIDENT (the next buffer's work queued on the device behind the
+ * device's doorbell).
  *
  *   gcc -std=c99 -O2 -Iinclude examples/percall_latency.c -Lpipe_amd/lib -lpipe_hip -lm \
  *       -Wl,-rpath,$PWD/pipe_amd/lib -o percall_latency && ./percall_latency [calls]
@@ -45,6 +47,12 @@ static int cmp(const void *a, const void *b)
 static pipe_hip_processor *make(int kind, const pipe_hip_config *cfg, const double *taps)
 {
     pipe_hip_processor *p = NULL, *st[2];
+    if (kind >= 5) { /* 5, 6: kinds 3, 4 with PIPE_HIP_PARAM_RELAXED_F64 (float64 buffers through the tile biquad) */
+        const double one = 1.0;
+        p = make(kind - 2, cfg, taps);
+        CHECK(pipe_hip_set_param(p, PIPE_HIP_PARAM_RELAXED_F64, &one, 1));
+        return p;
+    }
     if (kind == 0) {
         CHECK(pipe_hip_gain_create(cfg, 0.5, &p));
     } else if (kind == 1) {
@@ -74,7 +82,8 @@ static pipe_hip_processor *make(int kind, const pipe_hip_config *cfg, const doub
 int main(int argc, char **argv)
 {
     const int calls = argc > 1 ? atoi(argv[1]) : 3000, warm = 200;
-    static const char *names[5] = {"gain", "fir256", "chain fir256+gain", "biquad", "chain fir256+biquad+gain"};
+    static const char *names[7] = {"gain", "fir256", "chain fir256+gain", "biquad", "chain fir256+biquad+gain",
+                                   "biquad relaxed_f64", "chain fir256+biquad+gain relaxed_f64"};
     double taps[N], sum = 0;
     for (int k = 0; k < N; ++k) {  /* a windowed sinc, normalised */
         const double t = k - (N - 1) / 2.0, w = 0.5 - 0.5 * cos(2 * 3.14159265358979323846 * k / (N - 1));
@@ -95,10 +104,10 @@ int main(int argc, char **argv)
         cfg.lines = 1;
         cfg.max_batch = 1;
         void *in = malloc(es * F * C), *out_a = malloc(es * F * C), *out_b = malloc(es * F * C);
-        for (int kind = 0; kind < 5; ++kind) {
+        for (int kind = 0; kind < (dt == 0 ? 5 : 7); ++kind) {
             pipe_hip_processor *plain = make(kind, &cfg, taps), *res = make(kind, &cfg, taps);
             const double one = 1.0;
-            CHECK(pipe_hip_set_param(res, PIPE_HIP_PARAM_RESIDENT, &one, 1));
+            CHECK(pipe_hip_set_param(res, PIPE_HIP_PARAM_RESIDENT, &one, 1)); /* (the only handle that asks: never EBUSY) */
             double stats[2][3];
             int same = 1;
             for (int path = 0; path < 2; ++path) {

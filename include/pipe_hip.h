@@ -127,6 +127,20 @@ typedef enum pipe_hip_param {
                                    -- its successor is already queued on its state: pipe_hip_process answers
                                    PIPE_HIP_EHIP (a ProcessFunc error ends the run, pipe.go:438-440) and
                                    PIPE_HIP_ESTATE until the next pipe_hip_start. */
+    PIPE_HIP_PARAM_RELAXED_F64 = 6, /* 1 value: != 0 lets FLOAT64 buffers -- what the Go pipe carries (pipe.go:394,437) -- take
+                                  the biquad's time-segmented (tile) form as well, explicit opt-in per handle
+                                  (on a chain: for its biquad stages).  Why: the ordered recurrence is one
+                                  wave's dependent chain, 22 ns a frame whatever the chip -- 96 us per
+                                  4096 x 2 buffer where a host core needs 10; the tile form is one short
+                                  launch (per-call figures: DESIGN.md section 5) and can be queued ahead
+                                  (PIPE_HIP_PARAM_RESIDENT).  Price: results are no longer bit for bit the
+                                  oracle's float64 -- they differ by the recurrence's own rounding noise, at
+                                  most ~200 kappa * 2^-53 of the Line's full-scale output (kappa as under
+                                  PIPE_HIP_PARAM_EXACT; tested: |y - oracle| <= 256 kappa 2^-53 max|oracle|,
+                                  tests/test_gpu_biquad_seg.py) -- nine decimal orders below a float32 ulp.
+                                  PIPE_HIP_PARAM_EXACT wins over it.  Calls of fewer than 1024 frames, cascades
+                                  of more than two sections per tile pass and unstable sections keep the
+                                  ordered form as for float32. */
     PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
                                   biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
                                   up after limit_us -- the failure a preempted predecessor tile causes.  A

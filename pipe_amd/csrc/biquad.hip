@@ -1272,6 +1272,12 @@ public:
             exact_ = values[0] != 0.0;
             return PIPE_HIP_OK;
         }
+        if (param == PIPE_HIP_PARAM_RELAXED_F64 && count == 1 && values) {  // float64 results may take the relaxed forms too
+            relaxed_f64_ = values[0] != 0.0;
+            half_[0].reset();
+            half_[1].reset();
+            return PIPE_HIP_OK;
+        }
         if (param == PIPE_HIP_PARAM_DEBUG && count == 2 && values) {  // the next tile launch fails on demand
             debug_withhold_ = (int)values[0];
             debug_limit_us_ = values[1];
@@ -1298,7 +1304,7 @@ public:
     bool armable() const override { return S_ <= kTileMaxSections && cfg.channels <= 8; }
     bool armable_for(int64_t frames, int out_dtype) override
     {
-        if (exact_ || env_exact_ || out_dtype != PIPE_HIP_F32 || !relaxed_ok() || windowed() || ext_state_)
+        if (exact_ || env_exact_ || (out_dtype != PIPE_HIP_F32 && !relaxed_f64_) || !relaxed_ok() || windowed() || ext_state_)
             return false;
         const int64_t nseries = (int64_t)cfg.lines * cfg.channels;
         const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && nseries <= kTileLatencySeries;
@@ -1447,6 +1453,7 @@ public:
         return rc;
     }
     bool ordered_once_ = false;
+    bool relaxed_f64_ = false;  // PIPE_HIP_PARAM_RELAXED_F64: float64 buffers may take the time-segmented forms
     int debug_withhold_ = -1;
     double debug_limit_us_ = 0.0;
     // a gain stage that directly follows this biquad in a chain is folded into the
@@ -1486,7 +1493,7 @@ public:
         // time-segmented form: float32 results (or float64 intermediates of a float32 chain)
         // only, and only when the series alone cannot fill the machine
         // (the relaxed forms carry states through powers of the transition matrix: stable sections only)
-        const bool relaxed = !exact_ && !env_exact_ && !ordered_once_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) && relaxed_ok();
+        const bool relaxed = !exact_ && !env_exact_ && !ordered_once_ && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out || relaxed_f64_) && relaxed_ok();
         last_tile_.valid = false;
         last_oop_ = false;
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
@@ -2001,7 +2008,7 @@ public:
         for (int h = 0; h < 2; ++h)
             half_[h]->set_window(win_first, win_count);
         half_[0]->relaxed_f64_out = true;
-        half_[1]->relaxed_f64_out = relaxed_f64_out;
+        half_[1]->relaxed_f64_out = relaxed_f64_out || relaxed_f64_;
         half_[1]->set_post_gain(has_gain_, gain_);
         split_call_ = TileCall{d_in, d_out, in_dtype, out_dtype, frames, a.state, a.sstride, a.soff, (int)a.nseries, true, has_gain_, gain_};
         if (debug_withhold_ >= 0) {  // (halves made after the parameter was set)

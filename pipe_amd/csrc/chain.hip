@@ -166,7 +166,7 @@ public:
     {
         if (param == PIPE_HIP_PARAM_DEBUG && count == 2)
             return debug_fail_next((int)values[0], values[1]);
-        if (param == PIPE_HIP_PARAM_EXACT) {  // applies to every stage that has a relaxed form
+        if (param == PIPE_HIP_PARAM_EXACT || param == PIPE_HIP_PARAM_RELAXED_F64) {  // applies to every stage that has a relaxed form
             int rc = PIPE_HIP_EINVAL;
             for (auto &st : stages)
                 if (st->set_param(param, values, count) == PIPE_HIP_OK)

@@ -289,6 +289,11 @@ class Processor:
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         L.check(L.lib().pipe_hip_set_param(self._h, param, _dptr(v), v.size), "set_param")
 
+    def set_relaxed_f64(self, on: bool = True):
+        """PIPE_HIP_PARAM_RELAXED_F64: float64 buffers may take the biquad's tile form (explicit opt-in; the result
+        differs from the oracle's float64 by the recurrence's own rounding noise)."""
+        self._set_param(L.PARAM_RELAXED_F64, [1.0 if on else 0.0])
+
     def set_resident(self, on: bool = True, idle_ms: int = 0) -> bool:
         """PIPE_HIP_PARAM_RESIDENT: keep the next buffer's work queued on the device behind a doorbell, so that
         process() costs no kernel launch and no completion event (stages that can take a queued launch back:

@@ -357,6 +357,42 @@ def test_one_float32_pipe_buffer_per_call_takes_the_tile_form(sections):
         assert not ex.kernel_name().startswith("biquad_tile_kernel") and not b64.kernel_name().startswith("biquad_tile_kernel")
 
 
+@pytest.mark.parametrize("sections", [1, 2])
+def test_float64_buffers_take_the_tile_form_only_when_asked(sections):
+    """PIPE_HIP_PARAM_RELAXED_F64: the buffers the Go pipe carries (pipe.go:394,437: float64) may take the tile form
+    as an explicit opt-in -- per 4096 x 2 call one short launch instead of 96 us of ordered recurrence.  The bound as
+    include/pipe_hip.h states it: |y - oracle| <= 256 kappa 2^-53 max|oracle of the Line|.  Without the parameter, and
+    with PIPE_HIP_PARAM_EXACT on top of it, float64 buffers are bit for bit the oracle's.  Queued ahead
+    (PIPE_HIP_PARAM_RESIDENT) the same handle gives the same bits as on the plain path."""
+    q = coeffs(sections)
+    F, C, B = 4096, 2, 6
+    x = synth.samples(synth.line_seed(12), 0, B * F * C, np.float64).reshape(B, F, C)
+    want = oracle(q, x.reshape(1, B * F, C))[0].reshape(B, F, C)
+    bound = 256.0 * kappa(q) * 2.0 ** -53 * np.abs(want).max()
+    with P.Biquad(q, F, C, dtype=np.float64) as rel, P.Biquad(q, F, C, dtype=np.float64) as ex, \
+            P.Biquad(q, F, C, dtype=np.float64) as res:
+        for p in (rel, ex, res):
+            p.start()
+            p.set_relaxed_f64(True)
+        ex.set_exact(True)
+        assert res.set_resident(True)
+        worst = 0.0
+        for k in range(B):
+            got = rel.process(x[k])
+            assert rel.kernel_name().startswith("biquad_tile_kernel<f64,f64"), rel.kernel_name()
+            worst = max(worst, np.abs(got - want[k]).max())
+            assert np.array_equal(res.process(x[k]), got), k
+            assert np.array_equal(ex.process(x[k]), want[k])
+        assert worst <= bound, (worst, bound)
+        assert not ex.kernel_name().startswith("biquad_tile_kernel")
+        # a short buffer (the ordered form), then the stream goes on
+        tail = x[0, :300]
+        assert np.array_equal(rel.process(tail), res.process(tail))
+        rel.set_relaxed_f64(False)
+        rel.start()
+        assert np.array_equal(rel.process(x[0]), want[0])
+
+
 def test_a_tile_launch_that_gives_up_is_run_again_through_the_ordered_recurrence():
     """PIPE_HIP_PARAM_DEBUG on the biquad stage alone: the one-pass tile launch of a synchronous call fails on demand
     (tile 1 of every series publishes nothing); the carried state goes back to the copy tile 0 made of what it read
