@@ -23,7 +23,7 @@ N > 1 runs one rank per GPU, three ways to start them (the Lines each rank gets 
   3: configs[3], 512 Lines x 8 channels x 4096-frame buffers, FIR-256 -> biquad -> gain as one
     fused kernel; Line i on rank i mod N, and every Line advances by N buffers per step (one at N = 1):
     a rank's launch then always holds 512 Line-buffers and fills its GPU -- per-rank work constant,
-    "weak" (SURVEY.md 8d "C4"; `--buffers 1` gives the strong-scaling launch, `scale_projection` in the
+    "weak (K = G buffers per Line per step)" (SURVEY.md 8d "C4"; `--buffers 1` gives the strong-scaling launch, `scale_projection` in the
     N = 1 line says what each costs).
 Lines share no state (run.go:112-132): no data-path collective in any of them; RCCL carries only
 the barrier and the max-over-ranks of the timed region.
@@ -523,6 +523,10 @@ def run_rank(args, rank, world, local, sync, launch):
             "workload": workload, "baseline_config": cfg,
             "lines_total": total_lines, "lines_this_gpu": L, "channels": C, "buffer_frames": F,
             "buffers_per_step": K, "taps": N, "io_dtype": args.dtype,
+            # (the K plan of configs[3] on G ranks trades latency for scaling: a step hands back K buffers of every
+            # Line at once -- K - 1 buffers later than a one-buffer step would have delivered the first of them)
+            "added_latency_buffers": K - 1 if cfg == 3 else 0,
+            "added_latency_ms_of_signal": round((K - 1) * F / 48.0, 2) if cfg == 3 else 0.0,
             "parallelism": f"line-shard x{world}", "ranks": launch, "samples": "scalar (frames x channels)",
         },
         "mframes_per_s": round(value / C, 3),

@@ -35,7 +35,9 @@ def plan_buffers(config: int, world: int, buffers: Optional[int] = None, scaling
       config 1: 131072 (the whole stream of the step resident); config 2: 256;
       config 3: `world` -- with 512 / world Lines a one-buffer launch no longer fills a GPU (at 8 ranks:
       768 units for 2048 waves), so every rank's launch takes `world` buffers of each of its Lines: the
-      launch holds 512 Line-buffers whatever the rank count, per-rank work is constant ("weak").
+      launch holds 512 Line-buffers whatever the rank count, per-rank work is constant: weak scaling ON THE TIME
+      AXIS -- a step now delivers K buffers of every Line at once, i.e. K - 1 buffers (K - 1 times 85 ms of
+      signal at 48 kHz) of added latency per step; the label says so wherever the number is quoted.
     An explicit `buffers` keeps the label plan_lines gave (config 3 --buffers 1: strong scaling)."""
     if buffers:
         return int(buffers), scaling
@@ -43,7 +45,21 @@ def plan_buffers(config: int, world: int, buffers: Optional[int] = None, scaling
         return 131072, scaling
     if config == 2:
         return 256, scaling
-    return max(1, world), ("weak" if world > 1 else scaling)
+    k = max(1, world)
+    return k, (k_plan_label(k) if world > 1 else scaling)
+
+
+def k_plan_label(k: int) -> str:
+    """The `scaling` value of a config-3 run on the K plan (the driver's own default run is config 1: plain "weak")."""
+    return f"weak (K = {k} buffers per Line per step)"
+
+
+def step_units(config: int, rank: int, world: int, step: int, lines: Optional[int] = None, buffers: Optional[int] = None):
+    """The (Line, buffer index) pairs rank `rank` processes in step `step` (0-based) of bench.py --config N
+    --gpus world: its Lines (plan_lines) times the K consecutive buffers of the step (plan_buffers)."""
+    mine, _, scaling = plan_lines(config, rank, world, lines)
+    k, _ = plan_buffers(config, world, buffers, scaling)
+    return [(l, b) for l in mine for b in range(step * k, (step + 1) * k)]
 
 
 def rank_from_env() -> Tuple[int, int, int]:

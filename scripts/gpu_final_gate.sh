@@ -1,0 +1,38 @@
+#!/bin/bash
+# The last gpurun of a round: the GPU suite, smoke() and the default bench line of ONE tree -- the committed HEAD
+# (scripts/final_gate.sh checks that the tree is clean and passes the sha) -- with the sha256 of the libraries that ran.
+#   usage (on the GPU box, from the repo root):  scripts/gpu_final_gate.sh <head sha> [round tag]
+HEAD_SHA=${1:-unknown}; TAG=${2:-r05}
+OUT=gpurun_out/${TAG}_gate; mkdir -p $OUT
+R=$OUT/gate.txt
+{
+  echo "gate of $TAG: HEAD $HEAD_SHA"
+  echo "date (GPU box): $(date -u +%Y-%m-%dT%H:%M:%SZ)"
+  sha256sum pipe_amd/lib/libpipe_hip.so pipe_amd/lib/libpipe_host.so oracle/liboracle_pipe.so 2>/dev/null
+  sha256sum bench.py | sed 's/$/  (first 16 hex = bench_py_sha16)/'
+} > $R
+t0=$(date +%s)
+timeout 900 python -m pytest tests -q -m gpu > $OUT/pytest.txt 2>&1; rc_t=$?
+t1=$(date +%s)
+echo "pytest -m gpu: rc $rc_t in $((t1 - t0)) s: $(tail -1 $OUT/pytest.txt)" >> $R
+grep -E "^(FAILED|ERROR)" $OUT/pytest.txt | head -20 >> $R
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; rc_s=$?
+echo "smoke(): rc $rc_s: $(grep -E '^smoke' $OUT/smoke.txt | tail -1)" >> $R
+timeout 600 python bench.py --gpus 1 > $OUT/bench.txt 2> $OUT/bench.err; rc_b=$?
+echo "bench.py --gpus 1: rc $rc_b" >> $R
+python - "$OUT/bench.txt" >> $R <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r = d["roofline"]
+    print(f'  value {d["value"]} {d["unit"]}, ms_per_step {d["ms_per_step"]}, roofline.frac {r["frac"]}, kernel {r["kernel"]} '
+          f'avg {r["avg_kernel_ms"]} ms, traffic {r["traffic"]}')
+    for k in ("c4_chain", "c5_resampler_mix", "parity_stats"):
+        if k in d:
+            print(f"  {k}: " + json.dumps(d[k])[:600])
+    print(f'  cpu_baseline: {json.dumps(d.get("cpu_baseline"))[:300]}')
+except Exception as e:  # noqa: BLE001
+    print("  no bench line:", e)
+PY
+echo "verdict: $([ $rc_t -eq 0 ] && [ $rc_s -eq 0 ] && [ $rc_b -eq 0 ] && echo GREEN || echo RED)" >> $R
+cat $R

@@ -74,3 +74,30 @@ def test_library_has_no_vgpr_spills():
         pytest.skip("no hipcc")
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "check_spills.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_every_kernel_family_the_sources_can_report_is_asserted_by_a_test_that_never_skips():
+    """75 of the GPU tests force a variant through an A/B-only switch and skip against the library
+    that ships.  Mechanically: every kernel name the sources can hand to pipe_hip_kernel_name belongs to a family that
+    tests/test_gpu_kernel_families.py launches ON THE DEFAULT BUILD and asserts, and nothing in that file names an
+    A/B-only switch (conftest.AB_ONLY_RE: the rule by which tests are skipped)."""
+    import glob
+    import re
+    from tests import conftest
+    from tests import test_gpu_kernel_families as T
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "pipe_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pipe_amd", "csrc", "*.hpp")):
+        names.update(re.findall(r'"([a-z0-9_]+_kernel<[^"]*)"', open(f).read()))
+    assert len(names) > 40, names
+    def family(name):
+        base = name.split("<", 1)[0]
+        if base == "biquad_kernel" and "segmented" in name:
+            return "biquad_kernel<segmented>"          # the lane-walk time-segmented form: its own launch path
+        return base
+    families = {family(n) for n in names}
+    assert families == set(T.FAMILIES), (families ^ set(T.FAMILIES))
+    for fam, (_, prefix) in T.FAMILIES.items():
+        assert prefix.startswith(fam.split("<", 1)[0]), (fam, prefix)
+    src = open(T.__file__).read()
+    assert not conftest.AB_ONLY_RE.search(src)
+    assert "monkeypatch" not in src and "environ" not in src

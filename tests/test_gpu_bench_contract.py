@@ -100,14 +100,17 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
     # the K-per-rank plan (shard.plan_buffers): with 2 ranks every Line advances by 2 buffers per step, a rank's
     # launch holds 512 Line-buffers like the N = 1 launch -- per-rank work constant
-    assert "self-spawned" in d["config"]["ranks"] and d["scaling"] == "weak" and d["config"]["buffers_per_step"] == 2
+    assert "self-spawned" in d["config"]["ranks"] and d["config"]["buffers_per_step"] == 2
+    # ... which is weak scaling on the TIME axis, and the line says what it costs: one more buffer of latency per step
+    assert d["scaling"] == "weak (K = 2 buffers per Line per step)"
+    assert d["config"]["added_latency_buffers"] == 1 and abs(d["config"]["added_latency_ms_of_signal"] - 85.33) < 0.01
     # value counts BOTH ranks' samples: 512 Lines x 2 x 4096 x 8 per step over the slowest rank's time
     assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 2 * 4096 * 8) - 1.0) < 0.02
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 2 * 4096 * 8   # one rank's launch
     # --buffers 1: the strong-scaling launch (256 Lines x one buffer per rank)
     d = run_bench("--gpus", "2", "--config", "3", "--buffers", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
                   "--no-live-pmc", env={"PIPE_BENCH_DIST_BACKEND": "gloo"})
-    assert d["scaling"] == "strong" and d["config"]["buffers_per_step"] == 1
+    assert d["scaling"] == "strong" and d["config"]["buffers_per_step"] == 1 and d["config"]["added_latency_buffers"] == 0
     assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 4096 * 8) - 1.0) < 0.02
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * 256 * 4096 * 8
 
@@ -117,7 +120,7 @@ def test_threads_mode_is_one_process_with_a_thread_per_rank():
     d = run_bench("--gpus", "2", "--threads", "--config", "3", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
                   env={"PIPE_BENCH_SHARE_DEVICES": "1"})
     assert d["n_gpus"] == 2 and d["config"]["lines_total"] == 512 and d["config"]["lines_this_gpu"] == 256
-    assert "threads" in d["config"]["ranks"] and d["scaling"] == "weak"
+    assert "threads" in d["config"]["ranks"] and d["scaling"] == "weak (K = 2 buffers per Line per step)"
     assert abs(d["value"] * d["ms_per_step"] * 1e3 / (512 * 2 * 4096 * 8) - 1.0) < 0.02
     w = run_bench("--gpus", "2", "--threads", "--steps", "3", "--warmup", "1", "--buffers", "2048", "--no-cpu-baseline",
                   env={"PIPE_BENCH_SHARE_DEVICES": "1"})

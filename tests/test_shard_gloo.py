@@ -52,7 +52,7 @@ def _worker(rank, world, port, total_lines, out_dir):
     # Lines by the same K, and an explicit --buffers keeps the strong-scaling label
     got, tot, kind = shard.plan_lines(3, rank, world)
     K, kind = shard.plan_buffers(3, world, None, kind)
-    assert K == world and kind == "weak" and len(got) * K == 512
+    assert K == world and kind == shard.k_plan_label(world) and kind.startswith("weak") and len(got) * K == 512
     assert shard.sum_over_ranks(float(len(got) * K), dist) == 512 * world
     assert shard.plan_buffers(3, world, 1, "strong") == (1, "strong")
     assert shard.plan_buffers(2, world, None, "strong") == (256, "strong")
@@ -95,8 +95,28 @@ def test_k_per_rank_plan_fills_every_rank():
             mine, total, kind = shard.plan_lines(3, r, world)
             K, kind = shard.plan_buffers(3, world, None, kind)
             per_rank.append(len(mine) * K)
-            assert kind == ("weak" if world > 1 else "strong")
+            assert kind == (f"weak (K = {world} buffers per Line per step)" if world > 1 else "strong")
         assert per_rank == [512] * world
+
+
+def test_every_line_buffer_pair_is_processed_exactly_once_for_1_2_4_8_ranks():
+    """The K plan changes WHEN a (Line, buffer) is processed, never whether: over S steps on G ranks the union of the
+    ranks' units is every Line x every buffer of the first S * K, each exactly once -- for configs[3] (K = G), its
+    strong-scaling form (--buffers 1), configs[2] and the weak configs[1]."""
+    sys.path.insert(0, ROOT)
+    from collections import Counter
+    from pipe_amd import shard
+    for world in (1, 2, 4, 8):
+        for config, lines, buffers, steps in ((3, None, None, 3), (3, None, 1, 3), (2, None, 2, 2), (1, 2, 3, 2), (3, 37, None, 2)):
+            seen = Counter()
+            total = None
+            for r in range(world):
+                _, total, scaling = shard.plan_lines(config, r, world, lines)
+                k, _ = shard.plan_buffers(config, world, buffers, scaling)
+                for t in range(steps):
+                    seen.update(shard.step_units(config, r, world, t, lines, buffers))
+            want = {(l, b) for l in range(total) for b in range(steps * k)}
+            assert set(seen) == want and set(seen.values()) == {1}, (world, config, lines, buffers)
 
 
 def test_thread_ranks_barrier_and_reductions():
