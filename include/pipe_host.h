@@ -90,6 +90,15 @@ void pipe_host_free_values(double *values);
  * a running pipe recycles its buffers, so the count does not depend on how long the Lines are */
 int64_t pipe_host_pool_buffers_created(void);
 
+/* What a binding spends per ProcessFunc call on moving one frames x channels float64 buffer into its staging slice
+ * and the result back (pipe_amd/csrc/host/binding_cost.cpp): median microseconds over `reps` buffers,
+ *   out_us[0] one interface call per sample (what integration/go/hip/hip.go did until round 4), float64 staging
+ *   out_us[1] bulk copies (signal.ReadFloat64 / signal.WriteFloat64, mock/mock_test.go:120,128), float64 staging
+ *   out_us[2] / out_us[3] the same two with float32 staging (Options.Float32).
+ * staging_in / staging_out: frames x channels doubles each (pinned memory of the caller), or NULL. */
+int pipe_host_binding_cost(int32_t frames, int32_t channels, int32_t reps, double *staging_in, double *staging_out,
+                           double *out_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ type Options struct {
 	// a biquad buffer costs 27 us instead of 100 (the ordered float64 recurrence is one wave's issue).  Default
 	// false: float64 buffers, bit for bit the oracle's float64 chain.
 	Float32 bool
+	// RelaxedFloat64: float64 buffers (the pipe's own: pipe.go:394,437) may take the biquad's tile form
+	// (PIPE_HIP_PARAM_RELAXED_F64): per 4096 x 2 call 22 us instead of 95, results within 256 kappa 2^-53 of the
+	// Line's full scale of the ordered recurrence's instead of bit for bit.  Off by default.
+	RelaxedFloat64 bool
 }
 
 // Stage is one GPU Processor: its allocator before the Line is bound, its handle afterwards.
@@ -64,6 +68,7 @@ type Stage struct {
 	// overwrite whatever the allocator returns, so mutations must be made with THIS one)
 	inH, outH   []float64      // pinned staging, bufferSize * channels each (Options.Float32: inF / outF instead)
 	inF, outF   []float32
+	scratch     []float64      // Options.Float32: the float64 side of the conversion loops (bufferSize * max channels)
 	inP, outP   unsafe.Pointer // their C addresses
 	outChannels int
 }
@@ -109,35 +114,38 @@ func (o Options) config(bufferSize, channels, lines int) C.pipe_hip_config {
 	}
 }
 
-// signal.Floating <-> []float64.  v0.10.0 exposes per-sample accessors (the reference itself
-// fills buffers with SetSample, mock/mock.go:100-102); a raw-slice accessor would remove this hop.
+// signal.Floating <-> the pinned staging slice, in BULK: signal.ReadFloat64(src Floating, dst []float64) and
+// signal.WriteFloat64(src []float64, dst Floating) are what the reference's own tests move buffers with
+// (mock/mock_test.go:120,128).  Rounds 1-4 of this shim copied one Sample(i) / SetSample(i, v) interface call at a
+// time -- 16 384 calls per 4096 x 2 buffer, measured through the C++ stand-in at 26-28 us per buffer, MORE than the
+// 20 us device round trip it wraps; the bulk copies are 3.7 us (INTEGRATION.md "What the binding costs").
 func read(in signal.Floating, dst []float64) int {
 	n := in.Length() * in.Channels()
-	for i := 0; i < n; i++ {
-		dst[i] = in.Sample(i)
-	}
+	signal.ReadFloat64(in, dst[:n])
 	return in.Length()
 }
 
 func write(src []float64, out signal.Floating) {
-	for i, v := range src {
-		out.SetSample(i, v)
-	}
+	signal.WriteFloat64(src, out)
 }
 
-// the same through float32 staging (Options.Float32): the one rounding of the input happens here
-func read32(in signal.Floating, dst []float32) int {
+// the same through float32 staging (Options.Float32): one bulk read into a float64 scratch slice, then plain loops
+// over slices (no interface call per sample); the one rounding of the input happens here
+func (s *Stage) read32(in signal.Floating, dst []float32) int {
 	n := in.Length() * in.Channels()
-	for i := 0; i < n; i++ {
-		dst[i] = float32(in.Sample(i))
+	signal.ReadFloat64(in, s.scratch[:n])
+	for i, v := range s.scratch[:n] {
+		dst[i] = float32(v)
 	}
 	return in.Length()
 }
 
-func write32(src []float32, out signal.Floating) {
+func (s *Stage) write32(src []float32, out signal.Floating) {
+	w := s.scratch[:len(src)]
 	for i, v := range src {
-		out.SetSample(i, float64(v))
+		w[i] = float64(v)
 	}
+	signal.WriteFloat64(w, out)
 }
 
 func pinned32(n int) ([]float32, unsafe.Pointer, error) {
@@ -166,10 +174,20 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 		// must not leak the device handle (Close frees whatever exists, nil pointers included)
 		s.p, s.mctx, s.outChannels = p, mctx, int(ch)
 		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
+		if s.opts.RelaxedFloat64 && !s.opts.Float32 {
+			one := C.double(1)
+			// (a stage without a biquad in it answers PIPE_HIP_EINVAL: nothing to relax)
+			C.pipe_hip_set_param(p, C.PIPE_HIP_PARAM_RELAXED_F64, &one, 1)
+		}
 		if s.opts.Float32 {
 			if s.inF, s.inP, err = pinned32(bufferSize * in.Channels); err == nil {
 				s.outF, s.outP, err = pinned32(bufferSize * int(ch))
 			}
+			mc := in.Channels
+			if int(ch) > mc {
+				mc = int(ch)
+			}
+			s.scratch = make([]float64, bufferSize*mc)
 		} else {
 			if s.inH, s.inP, err = pinned(bufferSize * in.Channels); err == nil {
 				s.outH, s.outP, err = pinned(bufferSize * int(ch))
@@ -196,7 +214,7 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 			ProcessFunc: func(in, out signal.Floating) (int, error) {
 				var n int
 				if s.opts.Float32 {
-					n = read32(in, s.inF)
+					n = s.read32(in, s.inF)
 				} else {
 					n = read(in, s.inH)
 				}
@@ -206,7 +224,7 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 					return 0, err // the run ends with "error running: %w" (run.go:191-193)
 				}
 				if s.opts.Float32 {
-					write32(s.outF[:int(written)*s.outChannels], out)
+					s.write32(s.outF[:int(written)*s.outChannels], out)
 				} else {
 					write(s.outH[:int(written)*s.outChannels], out)
 				}
@@ -378,13 +396,17 @@ func (s *Stage) SetExact(on bool) mutable.Mutation {
 	return s.setParam(C.PIPE_HIP_PARAM_EXACT, []float64{v}, "set exact")
 }
 
-// SetResident keeps the NEXT buffer's work queued on the device ahead of its ProcessFunc call
-// (PIPE_HIP_PARAM_RESIDENT: behind a doorbell word in pinned host memory; the call then costs no kernel
-// launch and no completion event -- gain 12.6 -> 9.5 us, a 256-tap FIR on 4096 x 2 20.6 -> 16.0 us).
-// Stages that can take a queued launch back only (gain, FIR, chains of those): anything else answers an
-// error and stays on the plain path.  idle == 0: the library's 250 ms; work queued for longer than `idle`
-// without a call is taken back by the library (a queue waiting for its doorbell holds up device-wide
-// synchronisations).  Results are bit for bit those of the plain path.
+// SetResident asks for the device's DOORBELL for this stage: the NEXT buffer's work is then kept queued on the
+// device ahead of its ProcessFunc call (PIPE_HIP_PARAM_RESIDENT: behind a doorbell word in pinned host memory; the
+// call costs no kernel launch and no completion event -- gain 12.2 -> 9.3 us, a 256-tap FIR on 4096 x 2
+// 19.5 -> 15.7 us).  ONE stage per device can hold it (a parked queue costs every other parked queue of the process
+// tens of microseconds and holds up whatever shares its hardware queue: DESIGN.md section 5): give it to the stage
+// of the pipe that is called most, or fuse a Line's stages with hip.Chain and give it to the chain.  A stage that
+// asks while another one holds it stays on the plain path and the mutation reports ErrDoorbellBusy (not a failure of
+// the stream: errors.Is it and go on); stages that cannot take a queued launch back (the resampler, long biquad
+// cascades) report an error as well.  idle == 0: the library's 250 ms; work queued for longer than `idle` without a
+// call is dropped by the library (a queue waiting for its doorbell holds up device-wide waits of the process);
+// ResidentInfo counts such drops.  Results are bit for bit those of the plain path.
 func (s *Stage) SetResident(on bool, idle time.Duration) mutable.Mutation {
 	v := 0.0
 	if on {
@@ -393,7 +415,27 @@ func (s *Stage) SetResident(on bool, idle time.Duration) mutable.Mutation {
 			v = ms
 		}
 	}
-	return s.setParam(C.PIPE_HIP_PARAM_RESIDENT, []float64{v}, "set resident")
+	return s.mctx.Mutate(func() error {
+		d := C.double(v)
+		st := C.pipe_hip_set_param(s.p, C.PIPE_HIP_PARAM_RESIDENT, &d, 1)
+		if st == C.PIPE_HIP_EBUSY {
+			return ErrDoorbellBusy
+		}
+		return status(st, "set resident")
+	})
+}
+
+// ErrDoorbellBusy: another stage of the device holds the doorbell; this one keeps the plain path.
+var ErrDoorbellBusy = errors.New("pipe_hip: the device's doorbell is held by another stage")
+
+// ResidentInfo: does the stage hold its device's doorbell, and how many queued launches were run on stale input
+// and dropped -- by the idle watchdog / by another entry (a mutation, a short buffer, Start, Flush).  A host that
+// sees the first count grow feeds the stage slower than the idle limit.
+func (s *Stage) ResidentInfo() (holds bool, droppedByWatchdog, droppedByEntry int64) {
+	var h C.int32_t
+	var w, e C.int64_t
+	C.pipe_hip_resident_info(s.p, &h, &w, &e)
+	return h != 0, int64(w), int64(e)
 }
 
 // SetStageParam: parameter `param` (C.PIPE_HIP_PARAM_*) of stage `stage` of a Chain.

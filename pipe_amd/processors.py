@@ -432,6 +432,10 @@ class Chain(Processor):
             s._owned = True
         self.stages = list(stages)
 
+    def set_exact(self, exact: bool):
+        """PIPE_HIP_PARAM_EXACT on every stage that has a relaxed form: the staged chain of ordered forms."""
+        self._set_param(L.PARAM_EXACT, [1.0 if exact else 0.0])
+
     def set_stage_param(self, stage: int, param: int, values):
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         L.check(L.lib().pipe_hip_chain_set_param(self._h, int(stage), param, _dptr(v), v.size),
