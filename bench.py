@@ -138,7 +138,7 @@ PMC_KERNELS = {
     "main_ols": r"fir_ols32_kernel<float, float, 0",
     "main_chain": r"fir_ols32_kernel<float, float, [12]",
     "c4_chain": r"fir_ols32_kernel<float, float, [12]",
-    "c5_resampler": r"resample_(pair|tiled)_kernel<",
+    "c5_resampler": r"resample_(wave|pair|tiled)_kernel<",
     "biquad_alone": r"biquad_tile_kernel<float, float, 1, false, 3",
 }
 

@@ -443,6 +443,13 @@ struct PairRaw<float> {
     };
     U4 v;
     __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const U4 *>(p); }
+    // the piece at byte soff + voff of a raw buffer: out of range reads as zero (silence past the end of the input)
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+    {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v = __builtin_bit_cast(U4, (v4u)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    }
+    static constexpr unsigned kBytes = 16;
     __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
     {
         c0[0] = (double)v.x;
@@ -462,6 +469,13 @@ struct PairRaw<double> {
         a = *reinterpret_cast<const U2 *>(p);
         b = *reinterpret_cast<const U2 *>(p + 2);
     }
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+    {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        a = __builtin_bit_cast(U2, (v4u)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+        b = __builtin_bit_cast(U2, (v4u)__builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0));
+    }
+    static constexpr unsigned kBytes = 32;
     __device__ __forceinline__ void widen(double (&c0)[2], double (&c1)[2]) const
     {
         c0[0] = a.x;
@@ -693,6 +707,297 @@ __global__ void __launch_bounds__(kThreads) resample_pair_kernel(const PairArgs 
 #endif
 }
 
+// ---- the same two-outputs-per-lane form with NO workgroup: every wave on its own --------------------------------
+// What the pair kernel spends outside its tap loops (profiles/r03_resampler_phase_profile.txt: 47 % of a wave's time
+// -- tap table and first window per workgroup, request / deposit / barrier per tile, the third wave of every
+// workgroup half empty: 160 computing lanes in 192) comes from tiling the Line into workgroup-sized tiles.  Nothing in
+// the arithmetic needs a workgroup: a lane's two outputs read 26 frames, a wave's 64 lanes read ~142 consecutive
+// frames (1.1 KB of a float32 stereo stream).  Here a WAVE stages exactly that window for itself -- two or three
+// 16-byte pieces per lane, converted once, into its own two-channel float64 planes in LDS -- and runs the pair
+// kernel's tap loop on it.  LDS operations of one wave execute in order, so no barrier exists anywhere; the next
+// step's pieces are requested before the tap loop and deposited after it into the other pair of planes.
+// All 64 lanes compute.  A lane's taps must not change from step to step: G waves side by side cover 128 G outputs, a
+// whole number of periods of the phase pattern (G = up / gcd(up, 128): 5 for 160), wave w takes slot w mod G of
+// groups w / G, w / G + W / G, ... (W waves in the launch, a multiple of G), and the [G][2 T + 1][64] tap table gives
+// every slot its lanes' taps in one coalesced load per tap.  Same operations in the same order per output as every
+// other form: bit for bit the oracle's.
+struct WaveArgs {
+    ResampleArgs r;
+    int G;          // waves per group (slots)
+    int adv;        // input frames a group advances: 128 G down / up
+    int plane;      // plane stride (doubles)
+    int pieces;     // 2-frame pieces a wave's window holds (<= kPairVecs * 64)
+    int nvec;       // pieces every lane stages per step: ceil(pieces / 64)
+    int lead;       // virtual outputs ahead of the call's first one: groups start where the phase is 0
+    int groups_per_line;
+    int64_t nb;     // input frame (relative to this call) the first virtual output reads
+    int small_in;   // a Line's input is below 2 GiB: its frames are addressed through one raw buffer
+    const double *ptaps;  // [G][2 T + 1][64]
+    unsigned long long *prof;  // PH_RS_PROF builds: [wave][5] s_memtime ticks per phase
+};
+
+template <typename TIn, typename TOut, int TT, int DMIN>
+__global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *bufs = reinterpret_cast<double *>(smem_raw);  // [2 steps][2 channels][plane]
+    const ResampleArgs &a = t.r;
+    const int lane = (int)threadIdx.x;
+    constexpr int H = TT - 1;
+    constexpr int W = TT + DMIN + 1;  // frames a pair reads
+    constexpr int G4 = 4, NG = (W + G4 - 1) / G4, NPOS = NG * G4;
+    const int nwaves = (int)gridDim.x;
+    const int slot = (int)blockIdx.x % t.G;
+    const int ngroups = t.groups_per_line * a.lines, gstride = nwaves / t.G;
+#ifdef PH_RS_PROF
+    unsigned long long rsprof[5] = {}, rslast = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- the lane's two outputs (fixed for the whole launch): pair `q` of the group
+    const unsigned q = 64u * (unsigned)slot + (unsigned)lane;
+    const unsigned ttA = 2u * q * (unsigned)a.down, nA = ttA / (unsigned)a.up;
+    const unsigned nB = (ttA + (unsigned)a.down) / (unsigned)a.up;
+    const unsigned nA0 = (2u * 64u * (unsigned)slot * (unsigned)a.down) / (unsigned)a.up;  // lane 0's: the window's anchor
+    const bool e1 = (int)(nB - nA) - DMIN != 0;  // e = 1: output B reads X[0 .. T-1]; e = 0: X[1 .. T]
+    const int nrel = (int)(nA - nA0);
+    double hA[TT], hB[TT + 1];
+    auto load_taps = [&]() {
+        const double *__restrict__ tp = t.ptaps + (size_t)slot * (2 * TT + 1) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+            hA[j] = tp[j * 64];
+#pragma unroll
+        for (int i = 0; i <= TT; ++i)
+            hB[i] = tp[(TT + i) * 64];
+    };
+    // Everything about a step that does not depend on the lane -- scalar registers, computed ONCE per step (for the
+    // step after the one being computed) and carried: the PMC counts of the first version of this kernel
+    // (profiles/r05_resampler_pmc.txt: 234 vector and 161 scalar instructions per wave and step around 98 fma) said
+    // that the vector pipe was the bound and that more than half of its instructions were not the filter's.
+    // (plain scalars, not a struct: a struct carried around the loop went through 20 bytes of scratch per lane)
+    //   line, odd;  m0: the wave's first output, relative to the call's first (negative: virtual outputs);
+    //   base_e: the window's first staged frame, relative to the call's input (even);
+    //   interior: the window starts inside the call's input -- staged by raw buffer loads, no per-lane tests;
+    //   full: every output of the wave belongs to the call -- one 16-byte store per lane, no per-lane tests
+#define PH_RW_STEP(P, GID)                                                                            \
+    do {                                                                                              \
+        P##line = a.lines == 1 ? 0 : (GID) / t.groups_per_line;                                       \
+        const int g_ = (GID)-P##line * t.groups_per_line;                                             \
+        P##m0 = (int64_t)g_ * (128 * t.G) + 128 * slot - t.lead;                                      \
+        const int64_t base_ = t.nb + (int64_t)g_ * t.adv + (int64_t)nA0 - H - kPairPad;              \
+        P##base_e = base_ & ~(int64_t)1; /* even: 16-byte pieces of the input, 16-byte plane cells */ \
+        P##odd = (int)(base_ - P##base_e);                                                            \
+        P##interior = P##base_e >= 0 && t.small_in != 0;                                              \
+        P##full = P##m0 >= 0 && P##m0 + 128 <= a.out_frames;                                          \
+    } while (0)
+    int cs_line, cs_odd, ns_line = 0, ns_odd = 0;
+    int64_t cs_m0, cs_base_e, ns_m0 = 0, ns_base_e = 0;
+    bool cs_interior, cs_full, ns_interior = false, ns_full = false;
+    auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
+
+    // ---- staging, interior steps: the Line's input is ONE raw buffer, the window's start rides in the loads' scalar
+    // offset, a lane's offset is the same every step (k * 64 pieces further: the immediate offset), and a piece past
+    // the end of the input reads as zero by the buffer's own range check (silence past the end, as the slow path's).
+    // Every lane stages t.nvec pieces, no masks: the planes hold 128 t.nvec cells.
+    PairRaw<TIn> pre[kPairVecs];
+    // (a lane whose k-th piece lies beyond the window asks for an offset no buffer has: the range check answers zero
+    // and nothing is fetched -- without it every wave read 128 pieces where its window holds 73: 1.65 x the input)
+    unsigned voffk[kPairVecs];
+#pragma unroll
+    for (int k = 0; k < kPairVecs; ++k)
+        voffk[k] = lane + 64 * k < t.pieces ? (unsigned)(lane + 64 * k) * PairRaw<TIn>::kBytes : 0x7FFFFF00u;
+    auto request = [&](int line, int64_t base_e) {
+        const TIn *in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * 2;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(in), 0, bytes31(a.in_frames * 2 * (int64_t)sizeof(TIn)), 0x00020000);
+        const unsigned soff = (unsigned)base_e * 2u * (unsigned)sizeof(TIn);
+#pragma unroll
+        for (int k = 0; k < kPairVecs; ++k)
+            if (k < t.nvec)
+                pre[k].load_buf(rs, voffk[k], soff);
+    };
+    auto deposit = [&](double *dst) {
+#pragma unroll
+        for (int k = 0; k < kPairVecs; ++k)
+            if (k < t.nvec) {
+                double c0[2], c1[2];
+                pre[k].widen(c0, c1);
+                *reinterpret_cast<double2 *>(dst + 2 * (lane + k * 64)) = double2{c0[0], c0[1]};
+                *reinterpret_cast<double2 *>(dst + t.plane + 2 * (lane + k * 64)) = double2{c1[0], c1[1]};
+            }
+    };
+    // ---- staging, a Line's first steps (the window reaches into the history): frame by frame, on the spot
+    auto frame_value = [&](const TIn *__restrict__ in, const double *__restrict__ hist, int64_t g, int c) -> double {
+        if (g >= 0)
+            return g < a.in_frames ? (double)in[g * 2 + c] : 0.0;
+        return g >= -(int64_t)H ? hist[(g + H) * 2 + c] : 0.0;
+    };
+    auto stage_slow = [&](int line, int64_t base_e, double *dst) {
+        const TIn *__restrict__ in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * 2;
+        const double *__restrict__ hist = a.hist + (int64_t)line * H * 2;
+        for (int k = 0; k < t.nvec; ++k) {
+            const int pr = lane + k * 64;
+            const int64_t g = base_e + 2 * pr;
+            const double c00 = frame_value(in, hist, g, 0), c10 = frame_value(in, hist, g, 1);
+            const double c01 = frame_value(in, hist, g + 1, 0), c11 = frame_value(in, hist, g + 1, 1);
+            *reinterpret_cast<double2 *>(dst + 2 * pr) = double2{c00, c01};
+            *reinterpret_cast<double2 *>(dst + t.plane + 2 * pr) = double2{c10, c11};
+        }
+    };
+    // the planes of a step were written by this wave's own LDS stores: the LDS serves a wave's operations in order,
+    // the compiler must keep them in order too (a compiler barrier only: a fence would also wait for the step's global
+    // stores, a thousand cycles, every step)
+    auto order = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int gid = (int)blockIdx.x / t.G;
+    if (gid >= ngroups)
+        return;
+    PH_RW_STEP(cs_, gid);
+    int cur = 0;
+    if (cs_interior)
+        request(cs_line, cs_base_e);
+    load_taps();  // (behind the first window's requests: both fly together)
+    if (cs_interior)
+        deposit(bufs);
+    else
+        stage_slow(cs_line, cs_base_e, bufs);
+    order();
+    // The taps are IN their registers before the loop begins.  (Left to the compiler, the wait for their loads sits at
+    // their first use -- inside the loop, in the middle of the tap loop, as a wait for EVERY outstanding load: each
+    // step then waited there for the window it had just requested instead of computing under it.)
+#pragma unroll
+    for (int j = 0; j < TT; ++j)
+        asm volatile("" : "+v"(hA[j]));
+#pragma unroll
+    for (int i = 0; i <= TT; ++i)
+        asm volatile("" : "+v"(hB[i]));
+    PH_RS_STAMP(0);
+    typedef __attribute__((address_space(3))) const double *lds_ptr;
+    // A step's results are STORED AT THE TOP OF THE NEXT STEP, ahead of that step's window requests: the memory counter
+    // counts stores and loads alike and in order, so the wait for the requested pieces never waits for a younger store.
+    struct __attribute__((packed, aligned(sizeof(TOut)))) Quad {
+        TOut v[4];
+    };
+    Quad pend{};
+    TOut *po = nullptr;
+    int pflags = 0;  // bit 0: output A belongs to the call, bit 1: output B does; 4: every lane's both do (wave-uniform)
+    auto flush = [&]() {
+        if (pflags & 4) {  // (all but a Line's first and last wave: one store per lane, no tests)
+            *reinterpret_cast<Quad *>(po) = pend;
+        } else {
+            if (pflags & 1) {
+                po[0] = pend.v[0];
+                po[1] = pend.v[1];
+            }
+            if (pflags & 2) {
+                po[2] = pend.v[2];
+                po[3] = pend.v[3];
+            }
+        }
+        pflags = 0;
+    };
+    for (;;) {
+        flush();
+        const int next = gid + gstride;
+        const bool has_next = next < ngroups;
+        if (has_next) {
+            PH_RW_STEP(ns_, next);
+            if (ns_interior)
+                request(ns_line, ns_base_e);  // flies under this step's tap loop
+        }
+        PH_RS_STAMP(1);
+
+        // ---- the tap loop: every lane, also one whose outputs lie outside the call (its window is staged like any
+        // other; only the stores know)
+        const double *P0 = bufs + (size_t)cur * 2 * t.plane;
+        {
+            // plane cell of X[0] = x[base + H + kPairPad + nrel + DMIN + 1]; X[pos] sits pos cells below
+            const int idx0 = H + kPairPad + cs_odd + nrel + DMIN + 1;
+            const unsigned lo0 = (unsigned)(uintptr_t)(lds_ptr)(P0 + idx0 - (NPOS - 1));
+            const unsigned lo1 = lo0 + 8u * (unsigned)t.plane;
+            double accA0 = 0.0, accA1 = 0.0, accB0 = 0.0, accB1 = 0.0;
+            double v0[2][G4], v1[2][G4];
+            lds_read_pos<0, NPOS>(v0[0], lo0, std::make_integer_sequence<int, G4>{});
+            lds_read_pos<0, NPOS>(v1[0], lo1, std::make_integer_sequence<int, G4>{});
+            for_each_const(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g + 1 < NG) {
+                    lds_read_pos<(g + 1) * G4, NPOS>(v0[(g + 1) & 1], lo0, std::make_integer_sequence<int, G4>{});
+                    lds_read_pos<(g + 1) * G4, NPOS>(v1[(g + 1) & 1], lo1, std::make_integer_sequence<int, G4>{});
+                    lds_wait_cnt<2 * G4>();
+                } else {
+                    lds_wait_cnt<0>();
+                }
+                lds_pin(v0[g & 1]);
+                lds_pin(v1[g & 1]);
+#pragma unroll
+                for (int i = 0; i < G4; ++i) {
+                    const int pos = g * G4 + i;
+                    const double x0 = v0[g & 1][i], x1 = v1[g & 1][i];
+                    if (pos <= TT) {  // output B
+                        const double b0 = __builtin_fma(hB[pos < TT + 1 ? pos : 0], x0, accB0);
+                        const double b1 = __builtin_fma(hB[pos < TT + 1 ? pos : 0], x1, accB1);
+                        if (pos == 0) {
+                            accB0 = e1 ? b0 : accB0;
+                            accB1 = e1 ? b1 : accB1;
+                        } else if (pos == TT) {
+                            accB0 = e1 ? accB0 : b0;
+                            accB1 = e1 ? accB1 : b1;
+                        } else {
+                            accB0 = b0;
+                            accB1 = b1;
+                        }
+                    }
+                    if (pos >= DMIN + 1 && pos <= DMIN + TT) {  // output A
+                        accA0 = __builtin_fma(hA[pos - DMIN - 1 < TT && pos >= DMIN + 1 ? pos - DMIN - 1 : 0], x0, accA0);
+                        accA1 = __builtin_fma(hA[pos - DMIN - 1 < TT && pos >= DMIN + 1 ? pos - DMIN - 1 : 0], x1, accA1);
+                    }
+                }
+                // (as in the pair kernel: this group's fma stay ahead of the reads of the group after next)
+                asm volatile("" : "+v"(accA0), "+v"(accA1), "+v"(accB0), "+v"(accB1));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            const int64_t mA = cs_m0 + 2 * lane;  // the lane's output A, relative to the call's first
+            po = reinterpret_cast<TOut *>(a.out) + ((int64_t)cs_line * a.out_cap + mA) * 2;
+            pend.v[0] = (TOut)accA0;
+            pend.v[1] = (TOut)accA1;
+            pend.v[2] = (TOut)accB0;
+            pend.v[3] = (TOut)accB1;
+            pflags = cs_full ? 4 : ((mA >= 0 && mA < a.out_frames ? 1 : 0) | (mA + 1 >= 0 && mA + 1 < a.out_frames ? 2 : 0));
+        }
+        order();  // (this step's reads of the planes are done -- lgkmcnt(0) above; the next step's window goes to the OTHER planes)
+        PH_RS_STAMP(2);
+        if (!has_next)
+            break;
+        if (ns_interior)
+            deposit(bufs + (size_t)(cur ^ 1) * 2 * t.plane);
+        else
+            stage_slow(ns_line, ns_base_e, bufs + (size_t)(cur ^ 1) * 2 * t.plane);
+        order();
+        PH_RS_STAMP(3);
+        cur ^= 1;
+        cs_line = ns_line;
+        cs_odd = ns_odd;
+        cs_m0 = ns_m0;
+        cs_base_e = ns_base_e;
+        cs_interior = ns_interior;
+        cs_full = ns_full;
+        gid = next;
+    }
+    flush();
+#undef PH_RW_STEP
+#ifdef PH_RS_PROF
+    if (t.prof && lane == 0) {
+        unsigned long long *dst = t.prof + (size_t)blockIdx.x * 5;
+        for (int i = 0; i < 5; ++i)
+            dst[i] = rsprof[i];
+    }
+#endif
+}
+
 template <typename TIn>
 __global__ void resample_hist_kernel(const TIn *__restrict__ in, const double *__restrict__ hist_old,
                                      double *__restrict__ hist_new, int64_t frames, int H, int C)
@@ -726,6 +1031,11 @@ public:
         hist_bytes_ = sizeof(double) * (size_t)cfg.lines * (size_t)(T - 1) * (size_t)cfg.channels;
         PH_TRY(hist_[0].alloc(hist_bytes_));
         PH_TRY(hist_[1].alloc(hist_bytes_));
+        int n_cus = 0;
+        if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, cfg.device) == hipSuccess && n_cus > 0)
+            cus_ = n_cus;
+        else
+            (void)hipGetLastError();
         return start(stream);
     }
     void rate(int32_t *up, int32_t *down) const override
@@ -824,6 +1134,8 @@ public:
         }
         // 2-channel streams with the taps in registers: two adjacent outputs per lane share their
         // window reads (resample_pair_kernel)
+        if (total > 0 && n_out > 0 && launch_wave(a, in_dtype, out_dtype, reg_taps, s))
+            return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         if (total > 0 && n_out > 0 && launch_pair(a, in_dtype, out_dtype, reg_taps, s))
             return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         const bool big_lds = lds > 64 * 1024;
@@ -972,6 +1284,156 @@ private:
         return true;
     }
 
+    // the wave kernel's taps, [G][2 T + 1][64]: slot j, lane l is pair q = 64 j + l of the group
+    bool ensure_wave_taps(int G, int dmin)
+    {
+        if (wave_taps_.p && wave_G_ == G)
+            return true;
+        const size_t rows = (size_t)(2 * T_ + 1);
+        std::vector<double> h((size_t)G * rows * 64u, 0.0);
+        for (int j = 0; j < G; ++j)
+            for (int l = 0; l < 64; ++l) {
+                const int64_t qq = (int64_t)64 * j + l;
+                const int64_t ttA = 2 * qq * down_, ttB = ttA + down_;
+                const int nA = (int)(ttA / up_), pA = (int)(ttA % up_), nB = (int)(ttB / up_), pB = (int)(ttB % up_);
+                const int e = (nB - nA) - dmin;
+                double *row = h.data() + (size_t)j * rows * 64u + (size_t)l;
+                for (int k = 0; k < T_; ++k)
+                    row[(size_t)k * 64u] = host_proto_[(size_t)pA + (size_t)k * up_];
+                for (int i = 0; i <= T_; ++i) {
+                    const int k = i - 1 + e;
+                    row[(size_t)(T_ + i) * 64u] = k >= 0 && k < T_ ? host_proto_[(size_t)pB + (size_t)k * up_] : 0.0;
+                }
+            }
+        if (wave_taps_.alloc(sizeof(double) * h.size()) != PIPE_HIP_OK)
+            return false;
+        if (hipMemcpy(wave_taps_.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            wave_taps_.release();
+            return false;
+        }
+        wave_G_ = G;
+        return true;
+    }
+
+    // true when the wave kernel took the call (2 channels, taps in registers, down / up < 2, a group of at most
+    // kMaxWaveGroup waves covering whole periods of the phase pattern)
+    bool launch_wave(const ResampleArgs &a, int in_dtype, int out_dtype, bool reg_taps, hipStream_t s)
+    {
+        constexpr int kMaxWaveGroup = 160;
+        if (cfg.channels != 2 || !reg_taps || T_ % 4 != 0 || PH_ENV_AB("PIPE_HIP_RESAMPLE_NO_WAVE") || PH_ENV_AB("PIPE_HIP_RESAMPLE_NO_PAIR"))
+            return false;
+        const int dmin = down_ / up_;
+        if (dmin > 1)
+            return false;
+        int g = up_, b = 128;
+        while (b) {
+            const int r = g % b;
+            g = b;
+            b = r;
+        }
+        const int G = up_ / g;  // 128 G outputs are a multiple of `up`
+        if (G > kMaxWaveGroup)
+            return false;
+        if (reinterpret_cast<uintptr_t>(a.in) % dtype_size(in_dtype) != 0)
+            return false;
+        WaveArgs t{};
+        t.r = a;
+        t.G = G;
+        t.adv = (int)((int64_t)128 * G * down_ / up_);
+        // frames a wave stages: from lane 0's oldest (minus the pad) to lane 63's newest, rounded to pieces
+        const int span = (int)(((int64_t)126 * down_) / up_) + 1 + dmin + 1 + (T_ - 1) + kPairPad + 1 + 1;
+        t.pieces = (span + 1) / 2 + 1;
+        if (t.pieces > kPairVecs * 64)
+            return false;
+        t.nvec = (t.pieces + 63) / 64;
+        t.plane = 128 * t.nvec + 16;  // every lane stages nvec pieces, no masks; stride == 16 (mod 32): the channels' planes on distinct banks
+        if (!ensure_wave_taps(G, dmin))
+            return false;
+        t.ptaps = static_cast<const double *>(wave_taps_.p);
+        t.lead = (int)(a.out_total % up_);
+        t.nb = (a.out_total - t.lead) / up_ * down_ - a.in_total;
+        t.groups_per_line = (int)((t.lead + a.out_frames + 128 * (int64_t)G - 1) / (128 * (int64_t)G));
+        t.small_in = a.in_frames * 2 * (int64_t)dtype_size(in_dtype) < 0x7FFFFFFF ? 1 : 0;
+        const int64_t ngroups = (int64_t)t.groups_per_line * cfg.lines;
+        // twelve waves a CU (three a SIMD: the kernel's registers), whole groups of them
+        int64_t waves = ngroups * G;
+        const char *wpc = PH_ENV_AB("PIPE_HIP_RESAMPLE_WAVES_PER_CU");  // A/B: resident waves per CU
+        const int64_t cap = (int64_t)(wpc ? std::atoi(wpc) : 12) * cus_ / G * G;
+        if (waves > cap && cap >= G)
+            waves = cap;
+        const size_t lds = sizeof(double) * 4 * (size_t)t.plane;
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (timer.pair(&ev_a, &ev_b) != PIPE_HIP_OK)
+            return false;
+        const dim3 grid((unsigned)waves);
+#ifdef PH_RS_PROF
+        static DevBuf wprof;
+        if (!wprof.p && wprof.alloc(sizeof(unsigned long long) * 5 * 65536) != PIPE_HIP_OK)
+            return false;
+        t.prof = static_cast<unsigned long long *>(wprof.p);
+#endif
+#define PH_RW(TI, TO, TTV, DM) hipExtLaunchKernelGGL((resample_wave_kernel<TI, TO, TTV, DM>), grid, dim3(64), lds, s, ev_a, ev_b, 0, t)
+#define PH_RW_T(TI, TO, DM)                 \
+    switch (T_) {                           \
+    case 8: PH_RW(TI, TO, 8, DM); break;    \
+    case 12: PH_RW(TI, TO, 12, DM); break;  \
+    case 16: PH_RW(TI, TO, 16, DM); break;  \
+    case 24: PH_RW(TI, TO, 24, DM); break;  \
+    default: PH_RW(TI, TO, 32, DM); break;  \
+    }
+#define PH_RW_D(TI, TO)      \
+    if (dmin == 0) {         \
+        PH_RW_T(TI, TO, 0)   \
+    } else {                 \
+        PH_RW_T(TI, TO, 1)   \
+    }
+        if (in_dtype == PIPE_HIP_F32 && out_dtype == PIPE_HIP_F32) {
+            PH_RW_D(float, float)
+            last_kernel = "resample_wave_kernel<f32,f32>";
+        } else if (in_dtype == PIPE_HIP_F64 && out_dtype == PIPE_HIP_F64) {
+            PH_RW_D(double, double)
+            last_kernel = "resample_wave_kernel<f64,f64>";
+        } else if (in_dtype == PIPE_HIP_F32) {
+            PH_RW_D(float, double)
+            last_kernel = "resample_wave_kernel<f32,f64>";
+        } else {
+            PH_RW_D(double, float)
+            last_kernel = "resample_wave_kernel<f64,f32>";
+        }
+#undef PH_RW_D
+#undef PH_RW_T
+#undef PH_RW
+#ifdef PH_RS_PROF
+        {
+            static int launches = 0;
+            if (++launches == 15 && waves <= 65536) {
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> h((size_t)waves * 5);
+                (void)hipMemcpy(h.data(), t.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+                static const char *names[5] = {"taps + first window", "request next window", "tap loop + stores", "deposit next window", "-"};
+                double sum[5] = {}, tot = 0, mx = 0;
+                for (int64_t w = 0; w < waves; ++w) {
+                    double wt = 0;
+                    for (int i = 0; i < 5; ++i) {
+                        sum[i] += (double)h[(size_t)w * 5 + i];
+                        wt += (double)h[(size_t)w * 5 + i];
+                    }
+                    mx = wt > mx ? wt : mx;
+                }
+                for (double v : sum)
+                    tot += v;
+                std::fprintf(stderr, "[resampler wave prof] s_memtime ticks per wave, %lld waves, %lld groups of %d, %.1f steps a wave\n",
+                             (long long)waves, (long long)ngroups, G, (double)ngroups * G / (double)waves);
+                for (int i = 0; i < 4; ++i)
+                    std::fprintf(stderr, "[resampler wave prof]   %-22s %9.1f  %5.1f %%\n", names[i], sum[i] / (double)waves, 100.0 * sum[i] / tot);
+                std::fprintf(stderr, "[resampler wave prof]   %-22s %9.1f (slowest wave %9.1f)\n", "total", tot / (double)waves, mx);
+            }
+        }
+#endif
+        return hipGetLastError() == hipSuccess;
+    }
+
     // true when the pair kernel took the call
     bool launch_pair(const ResampleArgs &a, int in_dtype, int out_dtype, bool reg_taps, hipStream_t s)
     {
@@ -1107,6 +1569,9 @@ private:
     std::vector<double> host_proto_;
     DevBuf pair_taps_;
     int pair_ql_ = 0;
+    DevBuf wave_taps_;
+    int wave_G_ = 0;
+    int cus_ = 256;
     DevBuf proto_;
     DevBuf hist_[2];
     size_t hist_bytes_ = 0;

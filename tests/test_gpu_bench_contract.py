@@ -50,7 +50,7 @@ def test_default_line_has_every_contract_field():
     assert abs(c4["roofline_frac"] - c4["algorithmic_bytes_per_launch"] / (c4["avg_kernel_ms"] * 1e-3) / 8e12) < 1e-3
     c5 = d["c5_resampler_mix"]
     r5 = c5["resampler"]
-    assert r5["kernel"].startswith(("resample_pair_kernel", "resample_tiled_kernel")) and r5["in_frames"] == 1024 * 4096
+    assert r5["kernel"].startswith(("resample_wave_kernel", "resample_pair_kernel", "resample_tiled_kernel")) and r5["in_frames"] == 1024 * 4096
     assert r5["out_frames"] in (-(-1024 * 4096 * 160 // 147), 1024 * 4096 * 160 // 147)
     assert r5["algorithmic_bytes_per_launch"] == (r5["in_frames"] + r5["out_frames"]) * 2 * 4
     assert c5["mix"]["kernel"] == "mix_kernel<f32>" and 0 < c5["mix"]["roofline_frac"] < 1.0

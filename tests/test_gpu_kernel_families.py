@@ -104,6 +104,14 @@ def _resampler(channels, taps_per_phase):
     return run
 
 
+def _resampler_pair(P):
+    # 161 / 147: a group of the wave kernel would be 161 waves (161 is odd) -- the workgroup-tiled pair kernel takes it
+    proto = synth.resampler_proto(161, 147, 24)
+    with P.Resampler(proto, 24, 161, 147, F, 2, dtype=np.float32) as p:
+        p.start()
+        return _per_buffer(p, 3000, 2, np.float32)
+
+
 # family (the kernel name up to its template arguments) -> (how to reach it on the default build, what the name must start with)
 FAMILIES = {
     "gain_kernel": (_gain, "gain_kernel<f32,f32>"),
@@ -117,7 +125,8 @@ FAMILIES = {
     "biquad_lds_sp_kernel": (_biquad_lds_sp, "biquad_lds_sp_kernel<f64,f64>"),
     "biquad_tile_kernel": (_biquad_tile, "biquad_tile_kernel<f32,f32,segmented>"),
     "biquad_kernel<segmented>": (_biquad_lane_walk, "biquad_kernel<f32,f32,segmented>"),
-    "resample_pair_kernel": (_resampler(2, 24), "resample_pair_kernel<f32,f32>"),
+    "resample_wave_kernel": (_resampler(2, 24), "resample_wave_kernel<f32,f32>"),
+    "resample_pair_kernel": (_resampler_pair, "resample_pair_kernel<f32,f32>"),
     "resample_tiled_kernel": (_resampler(8, 24), "resample_tiled_kernel<f32,f32"),
     "resample_kernel": (_resampler(64, 48), "resample_kernel<f32,f32>"),
 }

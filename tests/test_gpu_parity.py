@@ -471,7 +471,7 @@ def test_resample_batch_at_the_bench_shape_windows_against_oracle():
         p.start()
         n_out = p.resample_batch(d_in, n_in, d_out, cap)
         torch.cuda.synchronize()
-        assert p.kernel_name().startswith("resample_pair_kernel")   # two adjacent outputs per lane
+        assert p.kernel_name().startswith("resample_wave_kernel")   # two adjacent outputs per lane, every wave on its own
         # a second launch continues the stream (what the bench's timed loop does)
         d_out2 = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
         n_out2 = p.resample_batch(d_in, n_in, d_out2, cap)
