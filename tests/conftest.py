@@ -83,7 +83,7 @@ AB_ONLY = (
     "PIPE_HIP_FIR_NO_MFMA", "PIPE_HIP_FIR_NO_PARTITION", "PIPE_HIP_FIR_PARTITION_SUM", "PIPE_HIP_FIR_R",
     "PIPE_HIP_FIR_RUN_FLOOR", "PIPE_HIP_FIR_WGS_PER_CU", "PIPE_HIP_OLS_MONO_ALONE", "PIPE_HIP_OLS_VARIANT",
     "PIPE_HIP_OVERLAP_TRACE", "PIPE_HIP_RESAMPLE_F64_PLANES", "PIPE_HIP_RESAMPLE_GATHER", "PIPE_HIP_RESAMPLE_LDS_TAPS",
-    "PIPE_HIP_RESAMPLE_NO_PAIR", "PIPE_HIP_RESAMPLE_NO_WAVE", "PIPE_HIP_RESAMPLE_PLANES",
+    "PIPE_HIP_RESAMPLE_NO_PAIR", "PIPE_HIP_RESAMPLE_NO_WAVE", "PIPE_HIP_RESAMPLE_WAVES_PER_CU", "PIPE_HIP_RESAMPLE_PLANES",
 )
 
 
