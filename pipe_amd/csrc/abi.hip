@@ -713,6 +713,10 @@ void pipe_hip_processor::Knobs::read()
         overlap_min_bytes = (size_t)std::atoll(e);
     if (const char *e = std::getenv("PIPE_HIP_ZERO_COPY_MAX"))
         zero_copy_max = (size_t)std::atoll(e);
+    if (const char *e = std::getenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS")) {
+        resample_rows_min_blocks = std::atoll(e);
+        resample_rows_stereo = true;
+    }
     if (const char *e = std::getenv("PIPE_HIP_BAR_UPLOAD"))
         bar_upload = e[0] != '0' ? 1 : 0;
 }

@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
+#include "resampler_rows.hpp"
 
 namespace pipehip {
 namespace {
@@ -1028,6 +1029,18 @@ public:
         PH_TRY(proto_.alloc(sizeof(double) * n));
         PH_HIP(hipMemcpy(proto_.p, proto, sizeof(double) * n, hipMemcpyHostToDevice));
         host_proto_.assign(proto, proto + n);
+        // the row form's table (resampler_rows.hip): row i = the taps of output i of a period, j ascending
+        if (cfg.channels >= 2 && cfg.channels <= 128 && (cfg.channels & (cfg.channels - 1)) == 0 &&
+            (T == 8 || T == 12 || T == 16 || T == 24)) {
+            std::vector<double> rt(n);
+            for (int i = 0; i < up; ++i) {
+                const int ph = (int)(((int64_t)i * down) % up);
+                for (int j = 0; j < T; ++j)
+                    rt[(size_t)i * T + j] = proto[(size_t)ph + (size_t)j * up];
+            }
+            PH_TRY(row_taps_.alloc(sizeof(double) * n));
+            PH_HIP(hipMemcpy(row_taps_.p, rt.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        }
         hist_bytes_ = sizeof(double) * (size_t)cfg.lines * (size_t)(T - 1) * (size_t)cfg.channels;
         PH_TRY(hist_[0].alloc(hist_bytes_));
         PH_TRY(hist_[1].alloc(hist_bytes_));
@@ -1134,6 +1147,8 @@ public:
         }
         // 2-channel streams with the taps in registers: two adjacent outputs per lane share their
         // window reads (resample_pair_kernel)
+        if (total > 0 && n_out > 0 && launch_rows(a, in_dtype, out_dtype, s))
+            return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         if (total > 0 && n_out > 0 && launch_wave(a, in_dtype, out_dtype, reg_taps, s))
             return finish_call(d_in, in_dtype, in_frames, n_out, a, s);
         if (total > 0 && n_out > 0 && launch_pair(a, in_dtype, out_dtype, reg_taps, s))
@@ -1313,6 +1328,103 @@ private:
             return false;
         }
         wave_G_ = G;
+        return true;
+    }
+
+    // true when the row kernel took the call (resampler_rows.hip): a power-of-two channel count, T one of the
+    // specialised sizes, a stream long enough that workgroups of 64 / C rows (B periods of the phase pattern each) fill the chip
+    bool launch_rows(const ResampleArgs &a, int in_dtype, int out_dtype, hipStream_t s)
+    {
+        if (!row_taps_.p || knobs.resample_rows_min_blocks < 0 || in_dtype != PIPE_HIP_F32 || out_dtype != PIPE_HIP_F32)
+            return false;
+        // Two channels: measured level with the wave kernel (0.29 / 0.37 of HBM streaming against 0.30 / 0.39 at 1 and 4
+        // Lines of 1024 buffers; 4 channels 0.34 against 0.21, 8 channels 0.31 - 0.37 against 0.16 - 0.23): stereo
+        // streams keep the wave kernel unless the threshold is set explicitly
+        if (cfg.channels == 2 && !knobs.resample_rows_stereo)
+            return false;
+        const int es = (int)dtype_size(in_dtype);
+        if (reinterpret_cast<uintptr_t>(a.in) % es != 0 || reinterpret_cast<uintptr_t>(a.out) % es != 0)
+            return false;
+        const int C = cfg.channels;
+        int lc = 0;
+        while ((2 << lc) < C)
+            ++lc;
+        const int rpb = 128 / C;
+        const int big = up_ > down_ ? up_ : down_;
+        const int B = big >= 144 ? 1 : 144 / big;
+        rows::Args t{};
+        t.lc = lc;
+        t.row_out = B * up_;
+        t.row_in = B * down_;
+        // LDS rows: the row's samples, room for a last 16-byte piece that overshoots, rows 16 bytes x an odd number apart
+        // (16-byte pieces in and out; a frame's 8-byte reads of 32 rows then fall two to a bank, once per frame: nothing)
+        auto stride_for = [&](int n) {
+            const int unit = C > 4 ? C : 4;  // (C channels: the rows of a 32-lane group land max(4, C) dwords x distinct numbers apart)
+            int st = (n + 4 + unit - 1) / unit * unit;
+            while ((st / unit) % 2 == 0)
+                st += unit;
+            return st;
+        };
+        t.in_stride = stride_for(t.row_in * C);
+        t.out_stride = stride_for(t.row_out * C);
+        t.out_off = (int)(((int64_t)(rpb + 1) * t.in_stride * es + 15) / 16 * 16);
+        const int64_t lds = (int64_t)t.out_off + (int64_t)rpb * t.out_stride * es + 16;
+        if (lds > 160 * 1024)
+            return false;
+        t.lds_bytes = (int)lds;
+        const int pei = 16 / es, npieces = (t.row_in * C + pei - 1) / pei;
+        t.piece_magic = (unsigned)(0x100000000ull / (unsigned)npieces) + 1u;
+        const int opieces = (t.row_out * C + pei - 1) / pei;
+        t.opiece_magic = (unsigned)(0x100000000ull / (unsigned)opieces) + 1u;
+        if ((int64_t)rpb * opieces >= 65536)
+            return false;
+        const int64_t first_row = a.out_total / t.row_out;
+        const int64_t last_row = (a.out_total + a.out_frames - 1) / t.row_out;
+        const int64_t rows_per_line = last_row - first_row + 1;
+        const int64_t blocks_per_line = (rows_per_line + rpb - 1) / rpb;
+        // whole workgroups of rows, and enough of them: the wave kernel keeps the short calls
+        if (rows_per_line * 4 < blocks_per_line * rpb * 3 || (int64_t)cfg.lines * blocks_per_line < knobs.resample_rows_min_blocks)
+            return false;
+        // 32-bit sample arithmetic in the kernel
+        if ((a.in_frames + (int64_t)(rpb + 2) * t.row_in + T_) * C * es >= 0x7FFFFFFF || (a.out_frames + (int64_t)(rpb + 2) * t.row_out) * C >= 0x7FFFFFFF)
+            return false;
+        // waves of a workgroup = segments of a row: twelve (three a SIMD: the kernel's registers), 8 outputs each at least
+        int segs = t.row_out / 8;
+        segs = segs > 12 ? 12 : segs < 1 ? 1 : segs;
+        if (const char *e = PH_ENV_AB("PIPE_HIP_RESAMPLE_ROWS_SEGS"))
+            segs = std::atoi(e);
+        t.seg_out = (t.row_out + segs - 1) / segs;
+        t.segs = (t.row_out + t.seg_out - 1) / t.seg_out;
+        t.seg_magic = (unsigned)(((int64_t)65536 * t.row_out + t.segs - 1) / t.segs);
+        if ((int)(((int64_t)t.segs * t.seg_magic) >> 16) != t.row_out || t.row_out >= 32768)
+            return false;
+        // a thread holds at most 8 pieces of a block's input in registers
+        if ((int64_t)(rpb + 1) * npieces > (int64_t)8 * 64 * t.segs || (int64_t)(rpb + 1) * npieces >= 65536)
+            return false;
+        const int per_cu = (int)((160 * 1024) / lds);
+        t.max_groups = cus_ * (per_cu < 1 ? 1 : per_cu);
+        t.in = a.in;
+        t.out = a.out;
+        t.hist = a.hist;
+        t.rtaps = static_cast<const double *>(row_taps_.p);
+        t.in_frames = a.in_frames;
+        t.out_frames = a.out_frames;
+        t.out_cap = a.out_cap;
+        t.up = up_;
+        t.down = down_;
+        t.lines = cfg.lines;
+        t.T = T_;
+        t.blocks_per_line = (int)blocks_per_line;
+        t.fb0 = (int)(first_row * t.row_in - a.in_total);
+        t.ob0 = (int)(first_row * t.row_out - a.out_total);
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (timer.pair(&ev_a, &ev_b) != PIPE_HIP_OK)
+            return false;
+        if (!rows::launch(t, in_dtype == PIPE_HIP_F64, out_dtype == PIPE_HIP_F64, s, ev_a, ev_b)) {
+            (void)hipGetLastError();
+            return false;
+        }
+        last_kernel = "resample_rows_kernel<f32,f32>";
         return true;
     }
 
@@ -1571,6 +1683,7 @@ private:
     int pair_ql_ = 0;
     DevBuf wave_taps_;
     int wave_G_ = 0;
+    DevBuf row_taps_;
     int cus_ = 256;
     DevBuf proto_;
     DevBuf hist_[2];

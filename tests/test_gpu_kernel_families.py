@@ -112,6 +112,21 @@ def _resampler_pair(P):
         return _per_buffer(p, 3000, 2, np.float32)
 
 
+def _resampler_rows(P):
+    # a resident 8-channel stream of 40 pipe buffers: 64 blocks of 16 rows (a period of the phase pattern each) and more
+    import torch
+    proto = synth.resampler_proto(160, 147, 24)
+    n = 40 * F
+    with P.Resampler(proto, 24, 160, 147, F, 8, dtype=np.float32, max_batch=40) as p:
+        p.start()
+        d_in = torch.zeros(n * 8, dtype=torch.float32, device="cuda")
+        cap = -(-n * 160 // 147) + 1
+        d_out = torch.empty(cap * 8, dtype=torch.float32, device="cuda")
+        p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        return p.kernel_name()
+
+
 # family (the kernel name up to its template arguments) -> (how to reach it on the default build, what the name must start with)
 FAMILIES = {
     "gain_kernel": (_gain, "gain_kernel<f32,f32>"),
@@ -126,6 +141,7 @@ FAMILIES = {
     "biquad_tile_kernel": (_biquad_tile, "biquad_tile_kernel<f32,f32,segmented>"),
     "biquad_kernel<segmented>": (_biquad_lane_walk, "biquad_kernel<f32,f32,segmented>"),
     "resample_wave_kernel": (_resampler(2, 24), "resample_wave_kernel<f32,f32>"),
+    "resample_rows_kernel": (_resampler_rows, "resample_rows_kernel<f32,f32>"),
     "resample_pair_kernel": (_resampler_pair, "resample_pair_kernel<f32,f32>"),
     "resample_tiled_kernel": (_resampler(8, 24), "resample_tiled_kernel<f32,f32"),
     "resample_kernel": (_resampler(64, 48), "resample_kernel<f32,f32>"),

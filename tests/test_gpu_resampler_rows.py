@@ -1,0 +1,119 @@
+"""The row form of the resampler (pipe_amd/csrc/resampler_rows.hip: a wave's lanes are the same output of different
+periods of the phase pattern, taps in scalar registers, the window in vector registers, a workgroup's stretch of the
+stream through LDS) against the CPU oracle, bit for bit: every ratio / tap count / sample type / channel count the form
+takes, streams cut into calls of unequal length (the call's first row starts mid-period, its window reaches into the
+history), several Lines, calls too short for it (another kernel keeps them).  The threshold knob is lowered so that
+sizes the oracle finishes in seconds take the form."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P = None
+torch = None
+
+
+def setup_module(module):
+    global P, torch
+    import torch as _t
+    from pipe_amd import processors as _p
+    assert _t.cuda.is_available(), "-m gpu tests need a GPU; refusing to pass silently"
+    P, torch = _p, _t
+
+
+def _tt(dtype):
+    return torch.float32 if dtype == np.float32 else torch.float64
+
+
+def _stream(p, ref_list, x, lens, cap, lines, C, dtype):
+    """x: [lines][frames][C]; feeds the calls of `lens` frames through resample_batch, returns the kernel names."""
+    names = []
+    pos = 0
+    for n in lens:
+        xin = np.ascontiguousarray(x[:, pos:pos + n, :])
+        d_in = torch.from_numpy(xin).cuda()
+        d_out = torch.full((lines * cap * C,), float("nan"), dtype=_tt(dtype), device="cuda")
+        n_out = p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        names.append(p.kernel_name())
+        got = d_out.cpu().numpy().reshape(lines, cap, C)
+        for l in range(lines):
+            want = ref_list[l].process(xin[l].astype(np.float64)).reshape(-1, C).astype(dtype)
+            assert want.shape[0] == n_out, (pos, n, l)
+            assert np.array_equal(got[l, :n_out], want), (pos, n, l, names[-1])
+            assert np.isnan(got[l, n_out:]).all(), (pos, n, l)   # nothing written past the call's outputs
+        pos += n
+    return names
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("up,down,T,C", [(160, 147, 24, 2), (147, 160, 24, 2), (2, 1, 16, 2), (1, 2, 32, 2), (3, 2, 12, 2), (160, 147, 8, 2),
+                                         (320, 147, 24, 2), (7, 5, 24, 2), (160, 147, 24, 8), (147, 160, 16, 4), (2, 1, 24, 16)])
+def test_rows_form_streams_bit_exact(monkeypatch, dtype, up, down, T, C):
+    monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
+    lines = 2
+    proto = synth.resampler_proto(up, down, T)
+    big = max(up, down)
+    row_in = down * (1 if big >= 144 else 144 // big)
+    rpb = 128 // C   # rows of a workgroup (a lane holds a pair of channels)
+    # calls: 6 workgroups of rows; a short one (another kernel's); 3.2 workgroups starting mid-row; 3.1 more
+    lens = [6 * rpb * row_in + 5, row_in // 2 + 1, 3 * rpb * row_in + rpb // 5 * row_in + 11, 3 * rpb * row_in + row_in]
+    total = sum(lens)
+    x = np.stack([synth.samples(synth.line_seed(40 + l), 0, total * C).reshape(total, C) for l in range(lines)]).astype(dtype)
+    refs = [O.Resampler(proto, T, up, down, C) for _ in range(lines)]
+    cap = -(-max(lens) * up // down) + 1
+    with P.Resampler(proto, T, up, down, 4096, C, dtype=dtype, lines=lines, max_batch=max(lens) // 4096 + 1) as p:
+        p.start()
+        names = _stream(p, refs, x, lens, cap, lines, C, dtype)
+    # float32 streams of up to 24 taps per phase take the form (float64: a block's stretch is twice a CU's LDS; 32 taps:
+    # the window alone is 128 registers; 320 / 147: 64 rows of 320 outputs do not fit the LDS): everybody else's values
+    # were checked just the same
+    takes = dtype == np.float32 and T <= 24 and up < 300
+    assert names[0].startswith("resample_rows_kernel") == takes, names
+    assert not names[1].startswith("resample_rows_kernel"), names   # half a row: not even one block of rows
+    assert names[2].startswith("resample_rows_kernel") == takes, names
+    assert names[3].startswith("resample_rows_kernel") == takes, names
+
+
+def test_rows_form_is_the_default_for_long_streams_of_four_channels_and_more():
+    """Default threshold: one 4096-frame pipe buffer stays on the tiled kernel, a long resident 8-channel stream takes
+    the rows; a stereo stream of the same length keeps the wave kernel (level with the rows: not switched)."""
+    up, down, T, F = 160, 147, 24, 4096
+    proto = synth.resampler_proto(up, down, T)
+    K = 40   # 64 blocks of 16 rows need 64 x 16 x 147 = 150 528 frames
+    n = K * F
+    for C, short_kernel, long_kernel in ((8, "resample_tiled_kernel", "resample_rows_kernel"), (2, "resample_wave_kernel", "resample_wave_kernel")):
+        x = synth.samples(synth.line_seed(51), 0, n * C).reshape(n, C).astype(np.float32)
+        cap = -(-n * up // down) + 1
+        ref = O.Resampler(proto, T, up, down, C)
+        with P.Resampler(proto, T, up, down, F, C, dtype=np.float32, max_batch=K) as p:
+            p.start()
+            got = p.process(x[:F], out_cap_frames=-(-F * up // down) + 1)
+            assert p.kernel_name().startswith(short_kernel), (C, p.kernel_name())
+            assert np.array_equal(got, ref.process(x[:F].astype(np.float64)).reshape(-1, C).astype(np.float32))
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
+            n_out = p.resample_batch(d_in, n, d_out, cap)
+            torch.cuda.synchronize()
+            assert p.kernel_name().startswith(long_kernel), (C, p.kernel_name())
+            want = ref.process(x.astype(np.float64)).reshape(-1, C).astype(np.float32)
+            assert n_out == want.shape[0]
+            assert np.array_equal(d_out.cpu().numpy()[: n_out * C].reshape(n_out, C), want)
+
+
+def test_rows_form_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "-1")
+    up, down, T, C, F, K = 160, 147, 24, 8, 4096, 40
+    proto = synth.resampler_proto(up, down, T)
+    n = K * F
+    d_in = torch.zeros(n * C, dtype=torch.float32, device="cuda")
+    cap = -(-n * up // down) + 1
+    d_out = torch.empty(cap * C, dtype=torch.float32, device="cuda")
+    with P.Resampler(proto, T, up, down, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_tiled_kernel")
