@@ -103,7 +103,7 @@ def usable_cores() -> int:
 
 
 KERNEL_SOURCES = ("ols_math.hpp", "ols32_core.hpp", "ols32_kernel.hpp", "fir_hist.hpp", "fir_ols32.hip",
-                  "fir_ols_impl.hpp", "chain_fused.hip", "fir_ols.hip", "resampler.hip", "Makefile")
+                  "fir_ols_impl.hpp", "chain_fused.hip", "fir_ols.hip", "resampler.hip", "resampler_rows.hip", "Makefile")
 
 
 def csrc_sha16() -> str:
@@ -783,6 +783,27 @@ def run_rank(args, rank, world, local, sync, launch):
             r5l.update({"lines": L5, "in_frames_per_line": n_in5l, "out_frames_per_line": gotl[0],
                         "msamples_out_per_s": round(L5 * gotl[0] * C / (ms5l * 1e-3) / 1e6, 1)})
             c5["resampler_64_lines"] = r5l
+        # the same stream with 8 channels (configs[3]'s Lines): 256 buffers of 4096 x 8 -- the same bytes per launch -- take
+        # the row form (resampler_rows.hip: lanes = periods of the phase pattern, taps in scalar registers)
+        C8, K8 = 8, K5 * C // 8
+        with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C8, dtype=np_dtype, device=local,
+                         max_batch=K8) as rs8:
+            rs8.start()
+            n_in8 = K8 * F
+            cap8 = -(-n_in8 * up5 // down5) + 1
+            got8 = [0]
+
+            def rs8_mk(a, b):
+                def call():
+                    got8[0] = rs8.resample_batch(a, n_in8, b, cap8, stream=stream)
+                return call
+            rs8_mk(d_src[:n_in8 * C8], arena[:cap8 * C8])()
+            torch.cuda.synchronize(dev)
+            by8 = (n_in8 + got8[0]) * C8 * 4
+            r8, ms8 = both(rs8, n_in8 * C8, cap8 * C8, 0, 200, 300, by8, mk_call=rs8_mk)
+            r8.update({"channels": C8, "in_frames": n_in8, "out_frames": got8[0],
+                       "msamples_out_per_s": round(got8[0] * C8 / (ms8 * 1e-3) / 1e6, 1)})
+            c5["resampler_8_channels"] = r8
         nm = got[0] * C
         with P.Mix(2, F, C, dtype=np_dtype, device=local, max_batch=cap5 // F + 1) as mx:
             mx.start()

@@ -434,6 +434,16 @@ bool launch_t(const Args &a, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
             for (int k = 0; k < 7; ++k)
                 std::fprintf(stderr, "[resampler rows prof]   %-32s %9.1f  %5.1f %%\n", names[k], sum[k] / (double)nw, 100.0 * sum[k] / tot);
             std::fprintf(stderr, "[resampler rows prof]   %-32s %9.1f (slowest wave %9.1f)\n", "total", tot / (double)nw, mx);
+            // by the wave's place in its workgroup (= its segment of the rows): refill + tap loops, and the wait behind them
+            for (int w = 0; w < a.segs; ++w) {
+                double t3 = 0, t4 = 0, t2 = 0;
+                for (unsigned g = 0; g < grid.x; ++g) {
+                    t2 += (double)h[((size_t)g * a.segs + w) * 8 + 2];
+                    t3 += (double)h[((size_t)g * a.segs + w) * 8 + 3];
+                    t4 += (double)h[((size_t)g * a.segs + w) * 8 + 4];
+                }
+                std::fprintf(stderr, "[resampler rows prof]   wave %2d: refill %8.1f tap loops %8.1f barrier behind %8.1f\n", w, t2 / grid.x, t3 / grid.x, t4 / grid.x);
+            }
         }
     }
 #endif

@@ -104,6 +104,35 @@ def test_rows_form_is_the_default_for_long_streams_of_four_channels_and_more():
             assert np.array_equal(d_out.cpu().numpy()[: n_out * C].reshape(n_out, C), want)
 
 
+@pytest.mark.parametrize("C", [2, 8])
+def test_rows_form_samples_that_are_not_finite(monkeypatch, C):
+    """Samples that are not finite: NaNs and infinities come out exactly where the oracle puts them (the form multiplies
+    nothing by a zero it was not given), everything else bit for bit."""
+    monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
+    up, down, T = 160, 147, 24
+    proto = synth.resampler_proto(up, down, T)
+    rpb = 128 // C
+    n = 5 * rpb * down + 17
+    x = synth.samples(synth.line_seed(60), 0, n * C).reshape(n, C).astype(np.float32)
+    x[100, 0] = np.inf               # first block
+    x[2 * rpb * down + 5, C - 1] = np.nan      # third block; the blocks between them are finite
+    x[n - 3, 0] = -np.inf            # last block
+    cap = -(-n * up // down) + 1
+    with P.Resampler(proto, T, up, down, 4096, C, dtype=np.float32, max_batch=n // 4096 + 1) as p:
+        p.start()
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((cap * C,), 7.0, dtype=torch.float32, device="cuda")
+        n_out = p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_rows_kernel")
+    with np.errstate(invalid="ignore"):
+        want = O.Resampler(proto, T, up, down, C).process(x.astype(np.float64)).reshape(-1, C).astype(np.float32)
+    got = d_out.cpu().numpy()[: n_out * C].reshape(n_out, C)
+    assert n_out == want.shape[0]
+    assert np.isnan(want).any() and np.isinf(want).any()
+    assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_rows_form_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "-1")
     up, down, T, C, F, K = 160, 147, 24, 8, 4096, 40
