@@ -1339,8 +1339,10 @@ private:
             return false;
         // Two channels: measured level with the wave kernel (0.29 / 0.37 of HBM streaming against 0.30 / 0.39 at 1 and 4
         // Lines of 1024 buffers; 4 channels 0.34 against 0.21, 8 channels 0.31 - 0.37 against 0.16 - 0.23): stereo
-        // streams keep the wave kernel unless the threshold is set explicitly
-        if (cfg.channels == 2 && !knobs.resample_rows_stereo)
+        // streams the wave kernel takes keep it unless the threshold is set explicitly; the ones it does not take (a phase
+        // pattern that more than 160 waves side by side would cover, e.g. up = 161: the workgroup-tiled pair kernel's,
+        // 0.245 at the bench shape) come here
+        if (cfg.channels == 2 && !knobs.resample_rows_stereo && wave_takes())
             return false;
         const int es = (int)dtype_size(in_dtype);
         if (reinterpret_cast<uintptr_t>(a.in) % es != 0 || reinterpret_cast<uintptr_t>(a.out) % es != 0)
@@ -1426,6 +1428,20 @@ private:
         }
         last_kernel = "resample_rows_kernel<f32,f32>";
         return true;
+    }
+
+    // the shapes launch_wave accepts (its first tests, without a call at hand)
+    bool wave_takes() const
+    {
+        if (cfg.channels != 2 || !(T_ == 8 || T_ == 12 || T_ == 16 || T_ == 24 || T_ == 32) || up_ > kThreads || down_ / up_ > 1)
+            return false;
+        int g = up_, b = 128;
+        while (b) {
+            const int r = g % b;
+            g = b;
+            b = r;
+        }
+        return up_ / g <= 160;
     }
 
     // true when the wave kernel took the call (2 channels, taps in registers, down / up < 2, a group of at most

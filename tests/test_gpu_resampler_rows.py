@@ -146,3 +146,27 @@ def test_rows_form_can_be_switched_off(monkeypatch):
         p.resample_batch(d_in, n, d_out, cap)
         torch.cuda.synchronize()
         assert p.kernel_name().startswith("resample_tiled_kernel")
+
+
+def test_stereo_streams_the_wave_kernel_does_not_take_come_to_the_rows_by_default():
+    """161 / 147: the wave kernel's group would be 161 waves wide; a long stereo stream of it takes the row form without
+    any knob (a short call keeps the workgroup-tiled pair kernel)."""
+    up, down, T, C, F, K = 161, 147, 24, 2, 4096, 160
+    proto = synth.resampler_proto(up, down, T)
+    n = K * F
+    x = synth.samples(synth.line_seed(52), 0, n * C).reshape(n, C).astype(np.float32)
+    cap = -(-n * up // down) + 1
+    ref = O.Resampler(proto, T, up, down, C)
+    with P.Resampler(proto, T, up, down, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        got = p.process(x[:F], out_cap_frames=-(-F * up // down) + 1)
+        assert p.kernel_name().startswith("resample_pair_kernel"), p.kernel_name()
+        assert np.array_equal(got, ref.process(x[:F].astype(np.float64)).reshape(-1, C).astype(np.float32))
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
+        n_out = p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_rows_kernel"), p.kernel_name()
+        want = ref.process(x.astype(np.float64)).reshape(-1, C).astype(np.float32)
+        assert n_out == want.shape[0]
+        assert np.array_equal(d_out.cpu().numpy()[: n_out * C].reshape(n_out, C), want)
