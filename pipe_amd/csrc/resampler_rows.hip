@@ -34,6 +34,7 @@
 // stretch of output leaves fully coalesced.  The workgroup walks blocks of rows; the next block's input flies (in
 // registers) under the current block's tap loops.
 // Same operations in the same order per output as every other form: bit for bit the oracle's.
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <utility>
@@ -393,12 +394,19 @@ bool launch_t(const Args &a, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b)
         return false;
     const_cast<Args &>(a).prof = prof;
 #endif
+    // (more than 64 KB of LDS is asked for once per device and instantiation, not once per launch)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return false;
 #define PH_RR(TTV)                                                                                            \
     do {                                                                                                      \
-        if (lds > 64 * 1024 &&                                                                                \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(resample_rows_kernel<TIn, TOut, TTV>),         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)          \
-            return false;                                                                                     \
+        static std::atomic<int> granted[64];                                                                  \
+        if ((int)lds > 64 * 1024 && granted[dev].load(std::memory_order_relaxed) < (int)lds) {                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(resample_rows_kernel<TIn, TOut, TTV>),     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
+                return false;                                                                                 \
+            granted[dev].store((int)lds, std::memory_order_relaxed);                                          \
+        }                                                                                                     \
         hipExtLaunchKernelGGL((resample_rows_kernel<TIn, TOut, TTV>), grid, block, lds, s, ev_a, ev_b, 0, a); \
     } while (0)
     switch (a.T) {
