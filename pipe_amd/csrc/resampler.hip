@@ -1369,8 +1369,12 @@ private:
         };
         t.in_stride = stride_for(t.row_in * C);
         t.out_stride = stride_for(t.row_out * C);
-        t.out_off = (int)(((int64_t)(rpb + 1) * t.in_stride * es + 15) / 16 * 16);
-        const int64_t lds = (int64_t)t.out_off + (int64_t)rpb * t.out_stride * es + 16;
+        t.out_off = (int)(((int64_t)(rpb + 1) * t.in_stride * es + 15) / 16 * 16);  // (two buffers of a block's input ...
+        int64_t lds = (int64_t)2 * t.out_off;
+        if (lds > 160 * 1024) {  // ... or one, and a second barrier a block, when the rows are that long)
+            lds = t.out_off;
+            t.out_off = 0;
+        }
         if (lds > 160 * 1024)
             return false;
         t.lds_bytes = (int)lds;

@@ -28,11 +28,13 @@
 // the stores 38 us, without the loads 34 (profiles/r05_resampler_rows_ablation.txt).  Half-used cache lines, every
 // frame fetched twice (a segment refills its window with the T - 1 frames ahead of it), and a launch that is ONE
 // round of waves, all loading, then all computing.  Now a WORKGROUP owns 128 / C consecutive rows -- one contiguous
-// stretch of the stream, 75 KB in and 82 KB out for 160 / 147: a CU's whole LDS -- loads it once, fully coalesced, into
-// LDS (rows padded apart so that the lanes' frame-t reads fall on distinct banks), its waves each compute one segment
-// of every row (the window's refill is LDS reads), park their results in LDS in the stream's own order, and the
-// stretch of output leaves fully coalesced.  The workgroup walks blocks of rows; the next block's input flies (in
-// registers) under the current block's tap loops.
+// stretch of the stream, 75 KB for 160 / 147 -- loads it once, fully coalesced, into LDS (rows padded apart so that
+// the lanes' frame-t reads spread over the banks), and its waves each compute one segment of every row (the window's
+// refill is LDS reads).  The workgroup walks blocks of rows; the next block's input flies (in registers) under the
+// current block's tap loops and is deposited into a SECOND buffer, so a block costs one barrier; the results leave
+// from the lanes as they are made (8 bytes per lane and output, 16 with two channels: a lane's consecutive outputs
+// are adjacent).  (The version before parked the results in LDS -- 82 KB beside ONE buffer of input -- for a fully
+// coalesced store behind a second barrier: load, deposit, tap loops, store followed each other.)
 // Same operations in the same order per output as every other form: bit for bit the oracle's.
 #include <atomic>
 #include <cstdint>
@@ -103,11 +105,12 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int H = TT - 1;
     constexpr int NC = TT / 4;
-    constexpr int PEI = 16 / (int)sizeof(TIn), PEO = 16 / (int)sizeof(TOut);  // samples per 16-byte piece
+    constexpr int PEI = 16 / (int)sizeof(TIn);  // samples per 16-byte piece
     const int C = 2 << a.lc;     // channels; a lane holds one PAIR of them (two independent fma chains)
     const int rpb = 64 >> a.lc;  // rows of a workgroup: lane = (row, pair)
-    TIn *const inb = reinterpret_cast<TIn *>(smem);                 // rows -1 .. rpb - 1, in_stride samples apart
-    TOut *const outb = reinterpret_cast<TOut *>(smem + a.out_off);  // rows 0 .. rpb - 1, out_stride samples apart
+    // two buffers of a block's input (rows -1 .. rpb - 1, in_stride samples apart): block b's in buffer b & 1
+    TIn *const inb0 = reinterpret_cast<TIn *>(smem);
+    TIn *const inb1 = reinterpret_cast<TIn *>(smem + a.out_off);  // (out_off == 0: rows so long that only ONE buffer fits -- a second barrier instead)
 
     const int lane = (int)threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
             }
         }
     };
-    auto deposit = [&]() {
+    auto deposit = [&](TIn *inb) {
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int idx = (int)threadIdx.x + u * (int)blockDim.x;
@@ -173,25 +176,28 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         }
     };
 
-    // Order of a turn: [barrier] tap loops of block b [barrier] block b + 1's input from registers into LDS, block
-    // b + 2's requested, THEN block b's output leaves.  (The wait for requested pieces is a wait for every older memory
-    // operation -- the compiler cannot count the stores of a loop -- so the stores come last: by the time the next
-    // pieces are waited for, a whole block of tap loops lies between.  With the stores first, every turn sat out its
-    // own stores' round trip before the next block could even be deposited: 30.5 us a launch, 22.5 without stores.)
+    // Order of a turn: [barrier: block b's input is complete in buffer b & 1] tap loops of block b, the results leaving
+    // from the lanes as they are made; then block b + 1's input from registers into the OTHER buffer (nobody reads it:
+    // its last readers were block b - 1's tap loops, and every wave was past those when it came to the barrier) and block
+    // b + 2's requested.  One barrier a block, no phase in which every wave stores, no results parked in LDS: the version
+    // before parked them (82 KB beside ONE buffer of input) for a fully coalesced store behind a second barrier --
+    // load, deposit, tap loops, store followed each other, the tap loops 55 % of a block's time.
 #ifdef PH_RR_PROF
     unsigned long long rrprof[8] = {}, rrlast = __builtin_amdgcn_s_memtime();
 #endif
     int b = (int)blockIdx.x;
+    int par = 0;
     if (PH_RR_ABLATE != 4 && b < nblocks) {
         request(b);
-        deposit();
+        deposit(inb0);
         if (b + (int)gridDim.x < nblocks)
             request(b + (int)gridDim.x);
     }
     PH_RR_STAMP(0);
-    for (; b < nblocks; b += (int)gridDim.x) {
+    for (; b < nblocks; b += (int)gridDim.x, par ^= 1) {
     __syncthreads();
     PH_RR_STAMP(1);
+    TIn *const inb = par ? inb1 : inb0;
     const int line = b / a.blocks_per_line;
     const int blk = b - line * a.blocks_per_line;
     const int obw = a.ob0 + blk * rpb * row_out;  // output 0 of the block's row 0, relative to the call's first output
@@ -211,7 +217,6 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         // samples (frame n of the lane's row, its pair of channels): n >= 0 in its own row, n < 0 at the end of the row above
         const TIn *const myin = inb + (row + 1) * a.in_stride + ch;
         const int above = a.in_stride - NE;
-        TOut *const myout = outb + row * a.out_stride + ch;
         struct alignas(2 * sizeof(TIn)) InPair {
             TIn x, y;
         };
@@ -252,8 +257,13 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         const TIn *src = myin + n_out * C;  // frame n_cur + 1
         InPair nx = *reinterpret_cast<const InPair *>(src);
         int n_cur = n_out - 1;  // the newest frame in the window (row-relative)
-        TOut *dst = myout + i0 * C;
-
+        // Results leave from the lane: (row, pair) lanes of one row write C / 2 x 8 adjacent bytes; with two channels a
+        // lane's consecutive outputs are adjacent, and two of them leave as one 16-byte store.
+        int go = obw + row * row_out + i0;  // the lane's output at hand, relative to the call's first
+        TOut *gdst = lout + (int64_t)go * C + ch;
+        const int out_frames = (int)a.out_frames;
+        OutPair pend{};
+        bool have = false;  // (wave-uniform: stereo only)
         for (;;) {
             for_each_const(std::make_integer_sequence<int, TT>{}, [&](auto qc) {
                 constexpr int r = (decltype(qc)::value + H) % TT;
@@ -292,8 +302,27 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
                     OutPair op;
                     op.x = (TOut)acc0;
                     op.y = (TOut)acc1;
-                    *reinterpret_cast<OutPair *>(dst) = op;
-                    dst += C;
+                    if (PH_RR_ABLATE == 3) {
+                    } else if (C != 2) {
+                        if ((unsigned)go < (unsigned)out_frames)
+                            *reinterpret_cast<OutPair *>(gdst) = op;
+                    } else if (!have) {
+                        pend = op;
+                        have = true;
+                    } else {
+                        struct __attribute__((packed, aligned(sizeof(TOut)))) Quad {
+                            OutPair a, b;
+                        };
+                        if ((unsigned)(go - 1) < (unsigned)out_frames && (unsigned)go < (unsigned)out_frames)
+                            *reinterpret_cast<Quad *>(gdst - C) = Quad{pend, op};
+                        else if ((unsigned)(go - 1) < (unsigned)out_frames)
+                            *reinterpret_cast<OutPair *>(gdst - C) = pend;
+                        else if ((unsigned)go < (unsigned)out_frames)
+                            *reinterpret_cast<OutPair *>(gdst) = op;
+                        have = false;
+                    }
+                    ++go;
+                    gdst += C;
                     ++i;
                     trow = tn;
                     tm += dr;
@@ -312,65 +341,20 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         // below the moment they are dead -- the late data then lands in an address (seen: writes to read-only
         // pages).  They are waited for while still the taps'.
         taps_wait(h);
+        if (have && (unsigned)(go - 1) < (unsigned)out_frames && PH_RR_ABLATE != 3)
+            *reinterpret_cast<OutPair *>(gdst - C) = pend;  // (a segment of an odd number of outputs)
         PH_RR_STAMP(3);
     }
-    __syncthreads();
-    PH_RR_STAMP(4);
 
-    // ---- the next block's input takes this one's place (every wave is past its tap loops), the one after is requested
+    // ---- the next block's input into the other buffer, the one after requested
+    if (a.out_off == 0)
+        __syncthreads();  // (one buffer: every wave is past its tap loops before the next block takes its place)
     if (PH_RR_ABLATE != 4 && b + (int)gridDim.x < nblocks) {
-        deposit();
+        deposit(par ? inb0 : inb1);
         if (b + 2 * (int)gridDim.x < nblocks)
             request(b + 2 * (int)gridDim.x);  // flies under the next block's tap loops
     }
     PH_RR_STAMP(5);
-    // ---- the block's stretch of the output leaves: NO samples a row in 16-byte pieces, piece idx = tid + u blockDim of
-    // the flat (row, piece) list; a batch's LDS reads are all issued before the first store
-    if (PH_RR_ABLATE != 3) {
-        const int NO = row_out * C;
-        const int opieces = (NO + PEO - 1) / PEO;
-        const int ototal = rpb * opieces;
-        const int64_t total = a.out_frames * C;
-        struct __attribute__((packed, aligned(sizeof(TOut)))) Q {
-            TOut s[PEO];
-        };
-        constexpr int UB = 2;
-        for (int base = (int)threadIdx.x; base < ototal; base += UB * (int)blockDim.x) {
-            v2u lo[UB], hi[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * (int)blockDim.x;
-                if (idx < ototal) {
-                    const int r = (int)__umulhi((unsigned)idx, a.opiece_magic);
-                    const v2u *sp = reinterpret_cast<const v2u *>(outb + r * a.out_stride + (idx - r * opieces) * PEO);
-                    lo[u] = sp[0];
-                    hi[u] = sp[1];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * (int)blockDim.x;
-                if (idx < ototal) {
-                    const int r = (int)__umulhi((unsigned)idx, a.opiece_magic);
-                    const int pc = idx - r * opieces;
-                    const int64_t e0 = (int64_t)(obw + r * row_out) * C + pc * PEO;  // the piece's first sample, relative to the call's output
-                    const int cnt = NO - pc * PEO < PEO ? NO - pc * PEO : PEO;      // (a row's last piece may be short)
-                    const Q q = __builtin_bit_cast(Q, v4u{lo[u].x, lo[u].y, hi[u].x, hi[u].y});
-                    if (cnt == PEO && e0 >= 0 && e0 + PEO <= total) {
-                        *reinterpret_cast<Q *>(lout + e0) = q;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < PEO; ++k)
-                            if (k < cnt && e0 + k >= 0 && e0 + k < total)
-                                lout[e0 + k] = q.s[k];
-                    }
-                }
-            }
-        }
-    }
-    PH_RR_STAMP(6);
-    // (the next block's tap loops overwrite the parked outputs: behind the barrier at the top, which no wave reaches
-    // before it has read its share of them)
     }
 #ifdef PH_RR_PROF
     if (a.prof && lane == 0) {

@@ -23,8 +23,8 @@ struct Args {
     int fb0;              // the first row's first input frame, relative to the call's input (<= 0 at a stream's start)
     int ob0;              // the first row's first output, relative to the call's first output (<= 0)
     int in_stride;        // LDS: samples between rows of the input (row_in C + pad, == C mod 2 C: frame-t reads on distinct banks)
-    int out_stride;       // LDS: samples between rows of the parked output (row_out C + pad, == C mod 2 C)
-    int out_off;          // LDS: byte offset of the parked output
+    int out_stride;       // (unused)
+    int out_off;          // LDS: byte offset of the second buffer of input
     int lds_bytes;
     unsigned piece_magic; // floor(2^32 / pieces of a row) + 1: idx / pieces by one multiplication (idx < 65536)
     unsigned opiece_magic;// the same for the pieces of a row of the output
