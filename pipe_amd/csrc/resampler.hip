@@ -1030,7 +1030,7 @@ public:
         PH_HIP(hipMemcpy(proto_.p, proto, sizeof(double) * n, hipMemcpyHostToDevice));
         host_proto_.assign(proto, proto + n);
         // the row form's table (resampler_rows.hip): row i = the taps of output i of a period, j ascending
-        if (cfg.channels >= 2 && cfg.channels <= 128 && (cfg.channels & (cfg.channels - 1)) == 0 &&
+        if (cfg.channels >= 2 && cfg.channels <= 128 && cfg.channels % 2 == 0 &&
             (T == 8 || T == 12 || T == 16 || T == 24)) {
             std::vector<double> rt(n);
             for (int i = 0; i < up; ++i) {
@@ -1331,7 +1331,7 @@ private:
         return true;
     }
 
-    // true when the row kernel took the call (resampler_rows.hip): a power-of-two channel count, T one of the
+    // true when the row kernel took the call (resampler_rows.hip): an even channel count, T one of the
     // specialised sizes, a stream long enough that workgroups of 64 / C rows (B periods of the phase pattern each) fill the chip
     bool launch_rows(const ResampleArgs &a, int in_dtype, int out_dtype, hipStream_t s)
     {
@@ -1348,20 +1348,19 @@ private:
         if (reinterpret_cast<uintptr_t>(a.in) % es != 0 || reinterpret_cast<uintptr_t>(a.out) % es != 0)
             return false;
         const int C = cfg.channels;
-        int lc = 0;
-        while ((2 << lc) < C)
-            ++lc;
-        const int rpb = 128 / C;
+        const int rpb = 64 / (C / 2);
         const int big = up_ > down_ ? up_ : down_;
         const int B = big >= 144 ? 1 : 144 / big;
         rows::Args t{};
-        t.lc = lc;
+        t.C = C;
+        t.rpb = rpb;
+        t.pair_rcp = (unsigned)((65536 + C / 2 - 1) / (C / 2));
         t.row_out = B * up_;
         t.row_in = B * down_;
         // LDS rows: the row's samples, room for a last 16-byte piece that overshoots, rows 16 bytes x an odd number apart
         // (16-byte pieces in and out; a frame's 8-byte reads of 32 rows then fall two to a bank, once per frame: nothing)
         auto stride_for = [&](int n) {
-            const int unit = C > 4 ? C : 4;  // (C channels: the rows of a 32-lane group land max(4, C) dwords x distinct numbers apart)
+            const int unit = C > 4 ? (C % 4 ? 2 * C : C) : 4;  // (rows a multiple of 16 bytes apart; C channels: the rows of a 32-lane group max(4, C) dwords x distinct numbers apart)
             int st = (n + 4 + unit - 1) / unit * unit;
             while ((st / unit) % 2 == 0)
                 st += unit;

@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
     constexpr int H = TT - 1;
     constexpr int NC = TT / 4;
     constexpr int PEI = 16 / (int)sizeof(TIn);  // samples per 16-byte piece
-    const int C = 2 << a.lc;     // channels; a lane holds one PAIR of them (two independent fma chains)
-    const int rpb = 64 >> a.lc;  // rows of a workgroup: lane = (row, pair)
+    const int C = a.C;      // channels (even); a lane holds one PAIR of them (two independent fma chains)
+    const int rpb = a.rpb;  // rows of a workgroup: lane = (row, pair), 64 / (C / 2) of them (6 channels: 21 rows, one lane idle)
     // two buffers of a block's input (rows -1 .. rpb - 1, in_stride samples apart): block b's in buffer b & 1
     TIn *const inb0 = reinterpret_cast<TIn *>(smem);
     TIn *const inb1 = reinterpret_cast<TIn *>(smem + a.out_off);  // (out_off == 0: rows so long that only ONE buffer fits -- a second barrier instead)
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
 #pragma unroll
                 for (int k = 0; k < PEI; ++k) {
                     const int e = e0 + k;
-                    const int g = e >= 0 ? e >> (a.lc + 1) : -((-e + C - 1) >> (a.lc + 1));  // floor(e / C)
+                    const int g = e >= 0 ? e / C : -((-e + C - 1) / C);  // floor(e / C)
                     const int c = e - g * C;
                     p.s[k] = g >= 0 ? (g < a.in_frames ? lin[(int64_t)g * C + c] : (TIn)0)
                                     : (g >= -H ? (TIn)lhist[(g + H) * C + c] : (TIn)0);  // (history frames ARE values of the input's type)
@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         int n_out = (int)(((int64_t)i0 * a.down) / up);              // newest frame output i reads (row-relative)
         int tm = (int)((int64_t)i0 * a.down - (int64_t)n_out * up);  // (i down) mod up
         const int dq = a.down / up, dr = a.down - dq * up;
-        const int row = lane >> a.lc, ch = 2 * (lane & ((C >> 1) - 1));
+        const int lrow = (int)(((unsigned)lane * a.pair_rcp) >> 16);  // lane / (C / 2)
+        const bool lane_on = lrow < rpb;                              // (a channel count that does not divide 128 leaves lanes over)
+        const int row = lane_on ? lrow : 0, ch = 2 * (lane - lrow * (C >> 1));
         // samples (frame n of the lane's row, its pair of channels): n >= 0 in its own row, n < 0 at the end of the row above
         const TIn *const myin = inb + (row + 1) * a.in_stride + ch;
         const int above = a.in_stride - NE;
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         // lane's consecutive outputs are adjacent, and two of them leave as one 16-byte store.
         int go = obw + row * row_out + i0;  // the lane's output at hand, relative to the call's first
         TOut *gdst = lout + (int64_t)go * C + ch;
-        const int out_frames = (int)a.out_frames;
+        const int out_frames = lane_on ? (int)a.out_frames : 0;  // (an idle lane's outputs are nobody's)
         OutPair pend{};
         bool have = false;  // (wave-uniform: stereo only)
         for (;;) {

@@ -15,7 +15,8 @@ struct Args {
     const double *rtaps;  // [up][T]: row i = the taps of output i of a period, proto[(i down mod up) + j up], j ascending
     int64_t in_frames, out_frames, out_cap;
     int up, down, lines, T;
-    int lc;               // log2 of the number of channel PAIRS (C = 2 .. 128, a power of two): a workgroup owns 128 / C rows, lane = (row, pair)
+    int C, rpb;           // channels (even, 2 .. 128) and rows of a workgroup's block: 64 / (C / 2), lane = (row, pair of channels)
+    unsigned pair_rcp;    // ceil(65536 / (C / 2)): lane / (C / 2) by one multiplication
     int row_out, row_in;  // a row: B periods of the phase pattern = B up outputs, B down input frames
     int seg_out, segs;    // wave w of a workgroup computes outputs [w seg_magic >> 16, (w + 1) seg_magic >> 16) of every row; segs waves
     unsigned seg_magic;   // ceil(65536 row_out / segs): (segs seg_magic) >> 16 == row_out

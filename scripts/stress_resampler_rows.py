@@ -28,11 +28,11 @@ for it in range(iters):
     g = math.gcd(up, down)
     up, down = up // g, down // g
     T = int(rng.choice([8, 12, 16, 24, 24, 32]))
-    C = int(rng.choice([2, 2, 4, 8, 16]))
+    C = int(rng.choice([2, 2, 4, 6, 8, 10, 16]))
     lines = int(rng.choice([1, 1, 2, 3]))
     big = max(up, down)
     row_in = down * (1 if big >= 144 else 144 // big)
-    rpb = 128 // C
+    rpb = 64 // (C // 2)
     F = 4096
     ncalls = int(rng.integers(1, 4))
     # calls of 0.8 .. 4 blocks of rows, not aligned to anything; now and then a short one in between

@@ -51,14 +51,14 @@ def _stream(p, ref_list, x, lens, cap, lines, C, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("up,down,T,C", [(160, 147, 24, 2), (147, 160, 24, 2), (2, 1, 16, 2), (1, 2, 32, 2), (3, 2, 12, 2), (160, 147, 8, 2),
-                                         (320, 147, 24, 2), (7, 5, 24, 2), (160, 147, 24, 8), (147, 160, 16, 4), (2, 1, 24, 16)])
+                                         (320, 147, 24, 2), (7, 5, 24, 2), (160, 147, 24, 8), (147, 160, 16, 4), (2, 1, 24, 16), (160, 147, 24, 6), (3, 2, 16, 12)])
 def test_rows_form_streams_bit_exact(monkeypatch, dtype, up, down, T, C):
     monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
     lines = 2
     proto = synth.resampler_proto(up, down, T)
     big = max(up, down)
     row_in = down * (1 if big >= 144 else 144 // big)
-    rpb = 128 // C   # rows of a workgroup (a lane holds a pair of channels)
+    rpb = 64 // (C // 2)   # rows of a workgroup's block (a lane holds a pair of channels)
     # calls: 6 workgroups of rows; a short one (another kernel's); 3.2 workgroups starting mid-row; 3.1 more
     lens = [6 * rpb * row_in + 5, row_in // 2 + 1, 3 * rpb * row_in + rpb // 5 * row_in + 11, 3 * rpb * row_in + row_in]
     total = sum(lens)
@@ -110,7 +110,7 @@ def test_rows_form_samples_that_are_not_finite(monkeypatch, C):
     monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
     up, down, T = 160, 147, 24
     proto = synth.resampler_proto(up, down, T)
-    rpb = 128 // C
+    rpb = 64 // (C // 2)
     n = 5 * rpb * down + 17
     x = synth.samples(synth.line_seed(60), 0, n * C).reshape(n, C).astype(np.float32)
     x[100, 0] = np.inf               # first block
