@@ -8,7 +8,7 @@ TAG=${1:-r05}
 if [ -n "$(git status --porcelain)" ]; then echo "tree is dirty: commit first"; git status --short | head; exit 1; fi
 ( cd pipe_amd/csrc && make -q ) || { echo "libpipe_hip.so is older than its sources: make first"; exit 1; }
 SHA=$(git rev-parse HEAD)
-/usr/local/graft/bin/gpurun --timeout 1800 -- "scripts/gpu_final_gate.sh $SHA $TAG" || exit 1
+for try in 1 2 3 4 5 6 7 8; do /usr/local/graft/bin/gpurun --timeout 1800 -- "scripts/gpu_final_gate.sh $SHA $TAG"; rc=$?; [ $rc -ne 3 ] && break; sleep 60; done; [ $rc -eq 0 ] || exit 1
 cp gpurun_out/${TAG}_gate/gate.txt profiles/${TAG}_gate.txt
 cp gpurun_out/${TAG}_gate/pytest.txt profiles/${TAG}_gate_pytest.txt
 git add profiles/${TAG}_gate.txt profiles/${TAG}_gate_pytest.txt && git commit -q -m "$TAG gate: suite + smoke + bench of $SHA on a fresh MI355X" && echo committed
