@@ -11,4 +11,5 @@ SHA=$(git rev-parse HEAD)
 for try in 1 2 3 4 5 6 7 8; do /usr/local/graft/bin/gpurun --timeout 1800 -- "scripts/gpu_final_gate.sh $SHA $TAG"; rc=$?; [ $rc -ne 3 ] && break; sleep 60; done; [ $rc -eq 0 ] || exit 1
 cp gpurun_out/${TAG}_gate/gate.txt profiles/${TAG}_gate.txt
 cp gpurun_out/${TAG}_gate/pytest.txt profiles/${TAG}_gate_pytest.txt
-git add profiles/${TAG}_gate.txt profiles/${TAG}_gate_pytest.txt && git commit -q -m "$TAG gate: suite + smoke + bench of $SHA on a fresh MI355X" && echo committed
+grep '^{' gpurun_out/${TAG}_gate/bench.txt | tail -1 > profiles/${TAG}_bench_default.json  # (the gate's own default bench line)
+git add profiles/${TAG}_gate.txt profiles/${TAG}_gate_pytest.txt profiles/${TAG}_bench_default.json && git commit -q -m "$TAG gate: suite + smoke + bench of $SHA on a fresh MI355X" && echo committed
