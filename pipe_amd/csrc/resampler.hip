@@ -1367,7 +1367,6 @@ private:
             return st;
         };
         t.in_stride = stride_for(t.row_in * C);
-        t.out_stride = stride_for(t.row_out * C);
         t.out_off = (int)(((int64_t)(rpb + 1) * t.in_stride * es + 15) / 16 * 16);  // (two buffers of a block's input ...
         int64_t lds = (int64_t)2 * t.out_off;
         if (lds > 160 * 1024) {  // ... or one, and a second barrier a block, when the rows are that long)
@@ -1379,10 +1378,6 @@ private:
         t.lds_bytes = (int)lds;
         const int pei = 16 / es, npieces = (t.row_in * C + pei - 1) / pei;
         t.piece_magic = (unsigned)(0x100000000ull / (unsigned)npieces) + 1u;
-        const int opieces = (t.row_out * C + pei - 1) / pei;
-        t.opiece_magic = (unsigned)(0x100000000ull / (unsigned)opieces) + 1u;
-        if ((int64_t)rpb * opieces >= 65536)
-            return false;
         const int64_t first_row = a.out_total / t.row_out;
         const int64_t last_row = (a.out_total + a.out_frames - 1) / t.row_out;
         const int64_t rows_per_line = last_row - first_row + 1;
@@ -1398,8 +1393,8 @@ private:
         segs = segs > 12 ? 12 : segs < 1 ? 1 : segs;
         if (const char *e = PH_ENV_AB("PIPE_HIP_RESAMPLE_ROWS_SEGS"))
             segs = std::atoi(e);
-        t.seg_out = (t.row_out + segs - 1) / segs;
-        t.segs = (t.row_out + t.seg_out - 1) / t.seg_out;
+        const int seg_out = (t.row_out + segs - 1) / segs;
+        t.segs = (t.row_out + seg_out - 1) / seg_out;
         t.seg_magic = (unsigned)(((int64_t)65536 * t.row_out + t.segs - 1) / t.segs);
         if ((int)(((int64_t)t.segs * t.seg_magic) >> 16) != t.row_out || t.row_out >= 32768)
             return false;

@@ -18,22 +18,20 @@ struct Args {
     int C, rpb;           // channels (even, 2 .. 128) and rows of a workgroup's block: 64 / (C / 2), lane = (row, pair of channels)
     unsigned pair_rcp;    // ceil(65536 / (C / 2)): lane / (C / 2) by one multiplication
     int row_out, row_in;  // a row: B periods of the phase pattern = B up outputs, B down input frames
-    int seg_out, segs;    // wave w of a workgroup computes outputs [w seg_magic >> 16, (w + 1) seg_magic >> 16) of every row; segs waves
+    int segs;             // waves of a workgroup; wave w computes outputs [w seg_magic >> 16, (w + 1) seg_magic >> 16) of every row
     unsigned seg_magic;   // ceil(65536 row_out / segs): (segs seg_magic) >> 16 == row_out
     int blocks_per_line;  // blocks of rows per Line: ceil(rows that hold outputs of this call / (128 / C))
     int fb0;              // the first row's first input frame, relative to the call's input (<= 0 at a stream's start)
     int ob0;              // the first row's first output, relative to the call's first output (<= 0)
-    int in_stride;        // LDS: samples between rows of the input (row_in C + pad, == C mod 2 C: frame-t reads on distinct banks)
-    int out_stride;       // (unused)
+    int in_stride;        // LDS: samples between rows of the input (row_in C + pad: the lanes' frame-t reads spread over the banks)
     int out_off;          // LDS: byte offset of the second buffer of input
     int lds_bytes;
     unsigned piece_magic; // floor(2^32 / pieces of a row) + 1: idx / pieces by one multiplication (idx < 65536)
-    unsigned opiece_magic;// the same for the pieces of a row of the output
     unsigned long long *prof;  // PH_RR_PROF builds: [wave][8] s_memtime ticks per phase
     int max_groups;       // workgroups resident on the device: a workgroup walks blocks blockIdx, + gridDim, ...
 };
 
-// true when a kernel was launched (T one of 8 / 12 / 16 / 24 / 32, input and output of one sample type); events as for hipExtLaunchKernelGGL
+// true when a kernel was launched (float32 in and out, T one of 8 / 12 / 16 / 24); events as for hipExtLaunchKernelGGL
 bool launch(const Args &a, int in_f64, int out_f64, hipStream_t s, hipEvent_t ev_a, hipEvent_t ev_b);
 
 }  // namespace rows
