@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
         struct alignas(2 * sizeof(TIn)) InPair {
             TIn x, y;
         };
-        struct alignas(2 * sizeof(TOut)) OutPair {
+        // (results go to global memory: the caller's buffer is aligned to an element, no more)
+        struct __attribute__((packed, aligned(sizeof(TOut)))) OutPair {
             TOut x, y;
         };
 

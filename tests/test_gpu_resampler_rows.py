@@ -169,3 +169,31 @@ def test_stereo_streams_the_wave_kernel_does_not_take_come_to_the_rows_by_defaul
         want = ref.process(x.astype(np.float64)).reshape(-1, C).astype(np.float32)
         assert n_out == want.shape[0]
         assert np.array_equal(d_out.cpu().numpy()[: n_out * C].reshape(n_out, C), want)
+
+
+@pytest.mark.parametrize("C", [2, 8])
+@pytest.mark.parametrize("off_in,off_out", [(1, 0), (0, 1), (3, 5)])
+def test_rows_form_buffers_aligned_to_an_element_only(monkeypatch, C, off_in, off_out):
+    """Device buffers that start at an odd element of their allocation (4-byte aligned, not 8 or 16)."""
+    monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
+    up, down, T = 160, 147, 24
+    proto = synth.resampler_proto(up, down, T)
+    rpb = 64 // (C // 2)
+    n = 3 * rpb * down + 29
+    x = synth.samples(synth.line_seed(61), 0, n * C).reshape(n, C).astype(np.float32)
+    cap = -(-n * up // down) + 1
+    with P.Resampler(proto, T, up, down, 4096, C, dtype=np.float32, max_batch=n // 4096 + 1) as p:
+        p.start()
+        big_in = torch.zeros(n * C + 8, dtype=torch.float32, device="cuda")
+        big_in[off_in:off_in + n * C] = torch.from_numpy(x.ravel()).cuda()
+        big_out = torch.full((cap * C + 16,), float("nan"), dtype=torch.float32, device="cuda")
+        d_in = big_in[off_in:off_in + n * C]
+        d_out = big_out[off_out:off_out + cap * C]
+        n_out = p.resample_batch(d_in, n, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_rows_kernel")
+    want = O.Resampler(proto, T, up, down, C).process(x.astype(np.float64)).reshape(-1, C).astype(np.float32)
+    assert n_out == want.shape[0]
+    got = big_out.cpu().numpy()
+    assert np.array_equal(got[off_out:off_out + n_out * C].reshape(n_out, C), want)
+    assert np.isnan(got[:off_out]).all() and np.isnan(got[off_out + n_out * C:]).all()   # nothing outside the call's outputs
