@@ -205,9 +205,8 @@ __global__ void __launch_bounds__(768) resample_rows_kernel(const Args a)
 
     // ---- the wave's segment: outputs [i0, i1) of every row; everything here is wave-uniform
     const int up = a.up;
-    // (segments of floor / ceil(row_out / waves) outputs: nobody waits at the barrier for a long one)
-    const int i0 = __builtin_amdgcn_readfirstlane((int)(((unsigned)wave * a.seg_magic) >> 16));
-    const int i1 = __builtin_amdgcn_readfirstlane((int)(((unsigned)(wave + 1) * a.seg_magic) >> 16));
+    // (resampler.hip's launch_rows cuts the row: equal segments)
+    const int i0 = a.seg_b[wave], i1 = a.seg_b[wave + 1];
     if (i0 < i1) {
         int i = i0;
         int n_out = (int)(((int64_t)i0 * a.down) / up);              // newest frame output i reads (row-relative)

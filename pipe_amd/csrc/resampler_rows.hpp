@@ -18,8 +18,8 @@ struct Args {
     int C, rpb;           // channels (even, 2 .. 128) and rows of a workgroup's block: 64 / (C / 2), lane = (row, pair of channels)
     unsigned pair_rcp;    // ceil(65536 / (C / 2)): lane / (C / 2) by one multiplication
     int row_out, row_in;  // a row: B periods of the phase pattern = B up outputs, B down input frames
-    int segs;             // waves of a workgroup; wave w computes outputs [w seg_magic >> 16, (w + 1) seg_magic >> 16) of every row
-    unsigned seg_magic;   // ceil(65536 row_out / segs): (segs seg_magic) >> 16 == row_out
+    int segs;             // waves of a workgroup (<= 16); wave w computes outputs [seg_b[w], seg_b[w + 1]) of every row
+    int seg_b[17];
     int blocks_per_line;  // blocks of rows per Line: ceil(rows that hold outputs of this call / (128 / C))
     int fb0;              // the first row's first input frame, relative to the call's input (<= 0 at a stream's start)
     int ob0;              // the first row's first output, relative to the call's first output (<= 0)
