@@ -668,6 +668,19 @@ int resident_enable(pipe_hip_processor *p, double value)
 }
 }  // namespace
 
+namespace pipehip {
+void ring_parked_before_free()
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (d >= 0 && d < kMaxDevices && g_door[d].owner)  // (a racy peek: the common case is no doorbell owner at all)
+        resident_ring_device(d, nullptr);
+}
+}  // namespace pipehip
+
 int pipe_hip_processor::enter()
 {
     PH_TRY(select_device());
@@ -1238,6 +1251,14 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         const int64_t produced = R.out_frames;
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
         R.state.store(RS::kIdle, std::memory_order_release);  // (rung by its own call: running, nothing parked)
+        if (!R.frees.empty()) {
+            // what the queued runs replaced: freed here, with nothing of ours parked (the free waits for launch k -- this
+            // one call does not queue its successor under it), so that a handle that stays on this path does not pile
+            // them up until its next ordinary entry
+            for (const DeferredFree &f : R.frees)
+                (void)(f.pinned ? hipHostFree(f.p) : hipFree(f.p));
+            R.frees.clear();
+        }
         int rc_next = resident_arm(p, in_frames);
         if (rc_next == kResidentUnsupported)  // (it worked a call ago: a runtime error of this call's successor)
             rc_next = PIPE_HIP_EHIP;

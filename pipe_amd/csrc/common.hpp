@@ -49,6 +49,10 @@ struct DeferredFree {
     bool pinned;
 };
 extern thread_local std::vector<DeferredFree> *g_deferred_frees;
+// Before a hipFree / hipHostFree of the calling thread's current device: work another handle has parked behind that
+// device's doorbell is rung (it runs on stale input and its owner takes it back), so that the free does not sit out
+// the 250 ms until the watchdog does it (abi.hip).
+void ring_parked_before_free();
 
 // Device allocation owned by a handle.
 struct DevBuf {
@@ -67,8 +71,10 @@ struct DevBuf {
     {
         if (p && g_deferred_frees)
             g_deferred_frees->push_back(DeferredFree{p, false});
-        else if (p)
+        else if (p) {
+            ring_parked_before_free();
             (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
     }
@@ -97,8 +103,10 @@ struct PinnedBuf {
     {
         if (p && g_deferred_frees)
             g_deferred_frees->push_back(DeferredFree{p, true});
-        else if (p)
+        else if (p) {
+            ring_parked_before_free();
             (void)hipHostFree(p);
+        }
         p = nullptr;
         bytes = 0;
     }
@@ -158,6 +166,12 @@ public:
     // marker packets and dispatch gap that begin()/end() around a launch include.  Both are
     // nullptr when profiling is off.
     int pair(hipEvent_t *a, hipEvent_t *b);
+    // hands the last pair() back: the launch it was taken for did not happen (never recorded, drain() must not read it)
+    void unpair(hipEvent_t a)
+    {
+        if (a && used_ > 0 && ring_[used_ - 1].a == a)
+            used_ -= 1;
+    }
     int collect(double *total_ms, int64_t *launches, bool reset);
 
 private:

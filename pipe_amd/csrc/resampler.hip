@@ -796,8 +796,8 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
     bool cs_interior, cs_full, ns_interior = false, ns_full = false;
     auto bytes31 = [](int64_t n) { return (int)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF); };
 
-    // ---- staging, interior steps: the Line's input is ONE raw buffer, the window's start rides in the loads' scalar
-    // offset, a lane's offset is the same every step (k * 64 pieces further: the immediate offset), and a piece past
+    // ---- staging, interior steps: what is left of the Line's input from the window's start on is ONE raw buffer (made
+    // per step from scalars), a lane's offset is the same every step (k * 64 pieces further: the immediate offset), and a piece past
     // the end of the input reads as zero by the buffer's own range check (silence past the end, as the slow path's).
     // Every lane stages t.nvec pieces, no masks: the planes hold 128 t.nvec cells.
     PairRaw<TIn> pre[kPairVecs];
@@ -808,14 +808,18 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
     for (int k = 0; k < kPairVecs; ++k)
         voffk[k] = lane + 64 * k < t.pieces ? (unsigned)(lane + 64 * k) * PairRaw<TIn>::kBytes : 0x7FFFFF00u;
     auto request = [&](int line, int64_t base_e) {
-        const TIn *in = reinterpret_cast<const TIn *>(a.in) + (int64_t)line * a.in_frames * 2;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(in), 0, bytes31(a.in_frames * 2 * (int64_t)sizeof(TIn)), 0x00020000);
-        const unsigned soff = (unsigned)base_e * 2u * (unsigned)sizeof(TIn);
+        // The buffer BEGINS at the window's first frame and holds what is left of the Line's input: the range check
+        // compares the vector offset (+ immediate) alone with the record count -- a scalar offset is added to the address
+        // unchecked, so a window start carried there would let a step's last pieces read past the Line's input (the next
+        // Line's samples, or past the allocation).  Scalar arithmetic per step, nothing per lane.
+        const int64_t left = a.in_frames - base_e;
+        const TIn *in = reinterpret_cast<const TIn *>(a.in) + ((int64_t)line * a.in_frames + (left > 0 ? base_e : 0)) * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<TIn *>(in), 0, left > 0 ? bytes31(left * 2 * (int64_t)sizeof(TIn)) : 0, 0x00020000);
 #pragma unroll
         for (int k = 0; k < kPairVecs; ++k)
             if (k < t.nvec)
-                pre[k].load_buf(rs, voffk[k], soff);
+                pre[k].load_buf(rs, voffk[k], 0u);
     };
     auto deposit = [&](double *dst) {
 #pragma unroll
@@ -1350,7 +1354,14 @@ private:
         const int C = cfg.channels;
         const int rpb = 64 / (C / 2);
         const int big = up_ > down_ ? up_ : down_;
-        const int B = big >= 144 ? 1 : 144 / big;
+        int B = big >= 144 ? 1 : 144 / big;
+        // A row's window refill reads the T - 1 frames ahead of the row out of the row directly ABOVE it (the kernel stages one
+        // row above a block, no more): a row must hold them.  Upsamplers by a large factor (up = 8, down = 1: 18 frames a row
+        // by the rule above; 160 / 3: 3 frames) take more periods a row.
+        if ((int64_t)B * down_ < T_ - 1)
+            B = (T_ - 1 + down_ - 1) / down_;
+        if ((int64_t)B * up_ >= 32768)
+            return false;
         rows::Args t{};
         t.C = C;
         t.rpb = rpb;
@@ -1366,6 +1377,8 @@ private:
                 st += unit;
             return st;
         };
+        if (t.row_in < T_ - 1)
+            return false;
         t.in_stride = stride_for(t.row_in * C);
         t.out_off = (int)(((int64_t)(rpb + 1) * t.in_stride * es + 15) / 16 * 16);  // (two buffers of a block's input ...
         int64_t lds = (int64_t)2 * t.out_off;
@@ -1391,8 +1404,10 @@ private:
         // waves of a workgroup = segments of a row: twelve (three a SIMD: the kernel's registers), 8 outputs each at least
         int segs = t.row_out / 8;
         segs = segs > 12 ? 12 : segs < 1 ? 1 : segs;
-        if (const char *e = PH_ENV_AB("PIPE_HIP_RESAMPLE_ROWS_SEGS"))
+        if (const char *e = PH_ENV_AB("PIPE_HIP_RESAMPLE_ROWS_SEGS")) {
             segs = std::atoi(e);
+            segs = segs > 12 ? 12 : segs < 1 ? 1 : segs;  // (the kernel's launch bound is 12 waves; seg_b has 17 entries)
+        }
         const int seg_out = (t.row_out + segs - 1) / segs;
         t.segs = (t.row_out + seg_out - 1) / seg_out;
         if (t.row_out >= 32768)
@@ -1407,6 +1422,9 @@ private:
             double g3[4] = {1.0, 1.0, 1.0, 1.0};
             if (e)
                 std::sscanf(e, "%lf,%lf,%lf,%lf", &g3[0], &g3[1], &g3[2], &g3[3]);
+            for (double &g : g3)
+                if (!(g > 0.0))
+                    g = 1.0;
             for (int k = 0; k < t.segs; ++k) {
                 w[k] = g3[k / 4 < 4 ? k / 4 : 3];
                 sum += w[k];
@@ -1444,6 +1462,7 @@ private:
             return false;
         if (!rows::launch(t, in_dtype == PIPE_HIP_F64, out_dtype == PIPE_HIP_F64, s, ev_a, ev_b)) {
             (void)hipGetLastError();
+            timer.unpair(ev_a);  // (never recorded: the next kernel takes a pair of its own)
             return false;
         }
         last_kernel = "resample_rows_kernel<f32,f32>";

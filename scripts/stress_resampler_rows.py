@@ -20,7 +20,7 @@ from pipe_amd import processors as P, synth  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 RATIOS = [(160, 147), (147, 160), (2, 1), (1, 2), (3, 2), (2, 3), (4, 3), (8, 7), (5, 4), (80, 147), (1, 1), (7, 5),
-          (147, 80), (256, 255), (3, 1), (161, 147), (441, 320), (40, 147)]
+          (147, 80), (256, 255), (3, 1), (161, 147), (441, 320), (40, 147), (8, 1), (16, 1), (160, 3)]
 t0 = time.time()
 kinds = {}
 for it in range(iters):
@@ -31,7 +31,7 @@ for it in range(iters):
     C = int(rng.choice([2, 2, 4, 6, 8, 10, 16]))
     lines = int(rng.choice([1, 1, 2, 3]))
     big = max(up, down)
-    row_in = down * (1 if big >= 144 else 144 // big)
+    row_in = down * max(1 if big >= 144 else 144 // big, -(-(T - 1) // down))
     rpb = 64 // (C // 2)
     F = 4096
     ncalls = int(rng.integers(1, 4))

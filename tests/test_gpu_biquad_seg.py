@@ -129,7 +129,7 @@ def test_segmented_matches_oracle_within_one_ulp(sections, lines, channels, fram
     (40, 1, 4096, 1),           # mono Lines of half a tile of 32-frame segments: tiles of 16-frame segments
     (7, 2, 2048 + 600, 2),      # the same choice with ragged calls
 ])
-def test_tiled_form_matches_oracle_within_one_ulp(sections, lines, channels, frames, calls, monkeypatch):
+def test_tiled_form_matches_oracle_within_one_ulp(sections, lines, channels, frames, calls, monkeypatch, ab_switch):
     """The LDS-tiled segmented form (up to 8 channels; one or two sections) on tile / segment boundaries; the
     lane-walk form on the same input gives the same bits almost everywhere (same contract, other segment lengths)."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
@@ -146,7 +146,8 @@ def test_tiled_form_matches_oracle_within_one_ulp(sections, lines, channels, fra
     d = np.abs(got.astype(np.float64) - want.astype(np.float64))
     assert np.all(d <= ulp), float((d / np.maximum(ulp, 1e-300)).max())
     assert np.count_nonzero(got != want) <= max(4, got.size // 100000)
-    monkeypatch.setenv("PIPE_HIP_BIQUAD_NO_TILE", "1")
+    if not ab_switch("PIPE_HIP_BIQUAD_NO_TILE", "1"):
+        return  # (A/B leg: the lane walk forced on a shape the tiles take)
     walk, name = run(q, x, lines, calls, exact=False)
     assert "biquad_kernel" in name, name
     assert np.count_nonzero(got != walk) <= max(4, got.size // 50000)
@@ -186,7 +187,7 @@ def test_tiled_form_in_a_staged_chain_folds_the_gain(shape, monkeypatch):
         assert np.count_nonzero(got[l] != want) <= 4
 
 
-def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact(monkeypatch):
+def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact(monkeypatch, ab_switch):
     """100 Hz, Q = 2 (kappa 55): relaxed, inside the kappa-scaled bound, and its measured distance is reported
     against it; 5 Hz, Q = 4 (kappa in the thousands): the ordered recurrence, bit for bit."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
@@ -195,14 +196,14 @@ def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact
     q = np.vstack([synth.biquad_rbj_lowpass(fc=100.0, q=2.0)])
     assert 40 < kappa(q) < 70
     for no_tile in ("", "1"):
-        if no_tile:
-            monkeypatch.setenv("PIPE_HIP_BIQUAD_NO_TILE", "1")
+        if no_tile and not ab_switch("PIPE_HIP_BIQUAD_NO_TILE", "1"):
+            continue  # (A/B leg: the lane walk on the same samples)
         got, name = run(q, x, lines, 2, exact=False)
         assert "segmented" in name and ("biquad_kernel" in name) == bool(no_tile), name
         want = oracle(q, x).astype(np.float32)
         d = np.abs(got.astype(np.float64) - want.astype(np.float64))
         assert np.all(d <= relaxed_ulp(q, want)), float((d / relaxed_ulp(q, want)).max())
-    monkeypatch.delenv("PIPE_HIP_BIQUAD_NO_TILE")
+    monkeypatch.delenv("PIPE_HIP_BIQUAD_NO_TILE", raising=False)
     q = np.vstack([synth.biquad_rbj_lowpass(fc=5.0, q=4.0)])
     assert kappa(q) > 1024
     got, name = run(q, x, lines, 2, exact=False)
@@ -212,7 +213,7 @@ def test_relaxed_bound_scales_with_kappa_and_ill_conditioned_cascades_stay_exact
 
 @pytest.mark.parametrize("sections", [3, 4])
 @pytest.mark.parametrize("lines,channels", [(1, 2), (3, 1), (2, 5), (40, 8)])
-def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channels, monkeypatch):
+def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channels, monkeypatch, ab_switch):
     """The tile kernel holds two sections: a cascade of 3 or 4 runs as its two halves, a float64 stream between
     them, the halves' states slices of the handle's own -- so a short call in the ordered form right after a
     long one (and a long one after that) continue the same state."""
@@ -240,7 +241,8 @@ def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channel
     d = np.abs(got.astype(np.float64) - want.astype(np.float64))
     assert np.all(d <= relaxed_ulp(q, want)), float((d / relaxed_ulp(q, want)).max())
     assert np.count_nonzero(got != want) <= max(4, got.size // 50000)
-    monkeypatch.setenv("PIPE_HIP_BIQUAD_NO_SPLIT", "1")
+    if not ab_switch("PIPE_HIP_BIQUAD_NO_SPLIT", "1"):
+        return  # (A/B leg: the whole cascade by lane walk)
     walk, name = run(q, x, lines, 1, exact=False)
     assert "two halves" not in name and "segmented" in name
     assert np.count_nonzero(walk != got) <= max(8, got.size // 25000)

@@ -61,7 +61,7 @@ def run_batch(taps, x, F, K, lines, exact):
                                                  (8, 1500, 2048, 6), (2, 2049, 300, 70),
                                                  (1, 1024, 1024, 24), (1, 2100, 512, 41), (1, 4096, 700, 9)])  # (one channel: two tiles per transform)
 @pytest.mark.parametrize("form", ["delay_line", "partition_sum"])
-def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, form, monkeypatch):
+def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, form, monkeypatch, ab_switch):
     """513 .. 4096 taps: several <= 512-tap spectra whose products are summed in the frequency domain
     (fir_ols32p.hip) -- as a frequency-domain delay line (one forward transform per 512-frame tile, the
     last P spectra in a ring: the shipped form) and as a sum over the partitions' own windows (A/B form).
@@ -71,7 +71,8 @@ def test_partitioned_ols_long_filters_within_one_ulp(channels, ntaps, F, K, form
     if form == "partition_sum":
         if channels == 1:
             pytest.skip("the A/B form takes channel pairs only")
-        monkeypatch.setenv("PIPE_HIP_FIR_PARTITION_SUM", "1")
+        if not ab_switch("PIPE_HIP_FIR_PARTITION_SUM", "1"):
+            pytest.skip("the partition-sum form exists in the A/B build only (the shipped form is `delay_line`)")
     lines = 2
     taps = synth.fir_lowpass_taps(ntaps, fc=0.11, f32_rounded=True)
     x = np.stack([synth.samples(synth.line_seed(80 + l), 0, K * F * channels, np.float32).reshape(K * F, channels)
@@ -306,14 +307,14 @@ def test_ols_item_dealing_shapes(lines, channels, frames, ntaps, monkeypatch):
 
 
 @pytest.mark.parametrize("ntaps,run_floor", [(1100, None), (2100, None), (1100, "4")])
-def test_partitioned_delay_line_many_short_lines_three_calls(ntaps, run_floor, monkeypatch):
+def test_partitioned_delay_line_many_short_lines_three_calls(ntaps, run_floor, monkeypatch, ab_switch):
     """The delay line's runs on many short Lines (runs as short as P tiles -- what fills the chip -- or,
     with the older floor of 4 P, longer than a Line's tiles; halves without a run; Lines ending inside a
     tile; every run opening with P - 1 warm-up windows out of the history) over three calls of different
     lengths: every Line against the oracle."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
-    if run_floor:
-        monkeypatch.setenv("PIPE_HIP_FIR_RUN_FLOOR", run_floor)
+    if run_floor and not ab_switch("PIPE_HIP_FIR_RUN_FLOOR", run_floor):
+        pytest.skip("the older run floor is an A/B-build switch (the shipped floor is the `None` parametrisation)")
     lines, C, F = 37, 4, 700
     taps = synth.fir_lowpass_taps(ntaps, fc=0.07, f32_rounded=True)
     calls = [3 * F, F, 5 * F - 13]
@@ -392,7 +393,7 @@ def test_mono_lines_ride_two_tiles_per_transform(calls, ntaps, monkeypatch):
     """One channel: a half-wave's complex sequence carries tile t and tile t + half-the-tiles of the same Line
     (fir_ols32_kernel<..., MONO>).  Odd and even tile counts, calls of one tile (the channel then rides alone),
     state carried from call to call, three Lines: within one ulp of the oracle like every overlap-save launch,
-    and the same samples as the channel-alone form (PIPE_HIP_OLS_MONO_ALONE) to within that bound."""
+    (the channel-alone form it replaced is an A/B-build variant)."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
     lines, C = 3, 1
     taps = synth.fir_lowpass_taps(ntaps, fc=0.09, f32_rounded=True)

@@ -51,13 +51,16 @@ def _stream(p, ref_list, x, lens, cap, lines, C, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("up,down,T,C", [(160, 147, 24, 2), (147, 160, 24, 2), (2, 1, 16, 2), (1, 2, 32, 2), (3, 2, 12, 2), (160, 147, 8, 2),
-                                         (320, 147, 24, 2), (7, 5, 24, 2), (160, 147, 24, 8), (147, 160, 16, 4), (2, 1, 24, 16), (160, 147, 24, 6), (3, 2, 16, 12)])
+                                         (320, 147, 24, 2), (7, 5, 24, 2), (160, 147, 24, 8), (147, 160, 16, 4), (2, 1, 24, 16), (160, 147, 24, 6), (3, 2, 16, 12),
+                                         # upsamplers by a large factor: a row of 144 / up periods would hold fewer than the T - 1 frames a window's
+                                         # refill reads out of the row above: rows of ceil((T - 1) / down) periods
+                                         (8, 1, 24, 4), (16, 1, 12, 8), (160, 3, 24, 4), (8, 1, 24, 2)])
 def test_rows_form_streams_bit_exact(monkeypatch, dtype, up, down, T, C):
     monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1")
     lines = 2
     proto = synth.resampler_proto(up, down, T)
     big = max(up, down)
-    row_in = down * (1 if big >= 144 else 144 // big)
+    row_in = down * max(1 if big >= 144 else 144 // big, -(-(T - 1) // down))
     rpb = 64 // (C // 2)   # rows of a workgroup's block (a lane holds a pair of channels)
     # calls: 6 workgroups of rows; a short one (another kernel's); 3.2 workgroups starting mid-row; 3.1 more
     lens = [6 * rpb * row_in + 5, row_in // 2 + 1, 3 * rpb * row_in + rpb // 5 * row_in + 11, 3 * rpb * row_in + row_in]
