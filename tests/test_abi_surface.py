@@ -76,6 +76,36 @@ def test_library_has_no_vgpr_spills():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_the_row_resamplers_hand_scheduled_tap_loads_are_waited_for():
+    """resampler_rows.hip's taps arrive through hand-written `s_load_dwordx8` statements the compiler does not know to
+    be loads (VERDICT r5 "weak" 9: a seen crash, nothing checked at build time).  scripts/check_rows_asm.sh walks the
+    disassembly: no instruction touches a load's registers before its `s_waitcnt lgkmcnt(0)`, no tap register is spilled;
+    and the checker itself must see a broken kernel (the same assembly with the hand-written waits taken out)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    script = os.path.join(ROOT, "scripts", "check_rows_asm.sh")
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "rows.s")
+        r = subprocess.run(["bash", script], capture_output=True, text=True, env=dict(os.environ, ROWS_ASM_KEEP=asm))
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines, out, k, dropped = open(asm).read().split("\n"), [], 0, 0
+        while k < len(lines):
+            if lines[k].strip() == ";;#ASMSTART" and k + 1 < len(lines) and lines[k + 1].strip().startswith("s_waitcnt lgkmcnt(0)"):
+                dropped += 1
+                k += 3
+                continue
+            out.append(lines[k])
+            k += 1
+        assert dropped >= 8
+        bad = os.path.join(d, "rows_bad.s")
+        open(bad, "w").write("\n".join(out))
+        r = subprocess.run(["bash", script, bad], capture_output=True, text=True)
+        assert r.returncode == 1 and "touches s[" in r.stdout, r.stdout + r.stderr
+
+
 def test_every_form_the_sources_can_report_is_compared_with_the_oracle_by_a_test_that_never_skips():
     """VERDICT r5 "weak" 1 / next 2.  Mechanically: every kernel label the sources can hand to pipe_hip_kernel_name,
     its element types taken out (a FORM: one launch path), is a key of tests/test_gpu_kernel_families.py::FORMS -- which
@@ -90,7 +120,12 @@ def test_every_form_the_sources_can_report_is_compared_with_the_oracle_by_a_test
         names.update(re.findall(r'"([a-z0-9_]+_kernel<[^"]*)"', open(f).read()))
     assert len(names) > 40, names
     forms = {T.form_of(n) for n in names}
-    assert forms == set(T.FORMS), (forms ^ set(T.FORMS))
+    assert not set(T.FORMS) & set(T.NOT_IN_THE_DEFAULT_BUILD)
+    assert forms == set(T.FORMS) | set(T.NOT_IN_THE_DEFAULT_BUILD), (forms ^ (set(T.FORMS) | set(T.NOT_IN_THE_DEFAULT_BUILD)))
+    for form, where in T.NOT_IN_THE_DEFAULT_BUILD.items():   # ... each with a named test that reaches it on the A/B build
+        path, _, fn = where.split(" ")[0].partition("::")
+        tsrc = open(os.path.join(ROOT, path)).read()
+        assert f"def {fn}(" in tsrc and form.split("<")[1].split(",")[-1].rstrip(">").strip() in tsrc, (form, where)
     src = open(T.__file__).read()
     assert not conftest.AB_ONLY_RE.search(src)
     assert "monkeypatch" not in src and "environ" not in src and "ab_switch" not in src and "skip" not in src

@@ -246,6 +246,13 @@ def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channel
     walk, name = run(q, x, lines, 1, exact=False)
     assert "two halves" not in name and "segmented" in name
     assert np.count_nonzero(walk != got) <= max(8, got.size // 25000)
+    # (A/B leg, the no-tile leg: the halves themselves by lane walk -- the one label the default build cannot report)
+    monkeypatch.delenv("PIPE_HIP_BIQUAD_NO_SPLIT")
+    assert ab_switch("PIPE_HIP_BIQUAD_NO_TILE", "1")
+    halves, name = run(q, x, lines, 1, exact=False)
+    assert name == "biquad_kernel<segmented, two halves of the cascade>", name
+    d = np.abs(halves.astype(np.float64) - want.astype(np.float64))
+    assert np.all(d <= relaxed_ulp(q, want))
 
 
 def test_calls_shorter_than_512_frames_keep_the_lane_walk(monkeypatch):

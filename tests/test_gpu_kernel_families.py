@@ -272,15 +272,6 @@ def _biquad_tile_halves(P):
     return name
 
 
-def _biquad_walk_halves(P):
-    x = sig(63, 8, 2 * F, 16)  # three sections over 16 channels: the halves by lane walk
-    with P.Biquad(Q3, 2 * F, 16, dtype=np.float32, lines=8, max_batch=1) as p:
-        p.start()
-        got, name = batch(p, x)
-    _check_biquad(got, x, Q3, (0, 7))
-    return name
-
-
 # form -> how to reach it on the default build (returns the label the call reported)
 FORMS = {
     "gain_kernel<>": _gain,
@@ -301,13 +292,23 @@ FORMS = {
     "biquad_tile_kernel<segmented>": _biquad_tile,
     "biquad_kernel<segmented>": _biquad_lane_walk,
     "biquad_tile_kernel<segmented, two halves of the cascade>": _biquad_tile_halves,
-    "biquad_kernel<segmented, two halves of the cascade>": _biquad_walk_halves,
     "resample_wave_kernel<>": _resampler(160, 147, 24, 2, 3000, 20),
     "resample_rows_kernel<>": _resampler_rows,
     "resample_pair_kernel<>": _resampler(161, 147, 24, 2, 3000, 21),  # a group of the wave kernel would be 161 waves
     "resample_tiled_kernel<>": _resampler(160, 147, 24, 3, 3000, 22),
     "resample_tiled_kernel<pairs>": _resampler(160, 147, 24, 8, 3000, 23),
     "resample_kernel<>": _resampler(160, 147, 48, 64, 1000, 24),
+}
+
+
+# Labels the sources hold that the default build cannot report, and why (tests/test_abi_surface.py adds them to FORMS when
+# it compares with the sources; the test that reaches each one through its A/B switch is named).
+NOT_IN_THE_DEFAULT_BUILD = {
+    # run_split (biquad.hip) is entered with <= 8 channels and >= tile_min_frames_ frames: both halves of the cascade then
+    # take the tile kernel (a half's transition matrix is a diagonal block of the cascade's: it is relaxed whenever the
+    # cascade is).  Only a switch that forbids the tile kernel leaves the halves to the lane walk.
+    "biquad_kernel<segmented, two halves of the cascade>":
+        "tests/test_gpu_biquad_seg.py::test_three_and_four_sections_run_as_two_tile_passes (the no-tile leg)",
 }
 
 
