@@ -140,6 +140,7 @@ PMC_KERNELS = {
     "c4_chain": r"fir_ols32_kernel<float, float, [12]",
     "c5_resampler": r"resample_(wave|pair|tiled)_kernel<",
     "biquad_alone": r"biquad_tile_kernel<float, float, 1, false, 3",
+    "headline_f64": r"fir_ols32_kernel<double, double, 0",
 }
 
 
@@ -201,13 +202,13 @@ def live_pmc(args, want):
 
 class PowerLog:
     """Socket power and shader clock from the amdgpu hwmon nodes (what scripts/clock_log.py reads), sampled
-    by a thread while a loaded window runs.  Every card in sysfs is sampled; the one whose median power is
-    highest under load is this process's GPU (a box may list more cards than HIP sees)."""
+    by a thread while a loaded window runs: the card at this process's PCI address (sysfs_card_of); where that cannot
+    be told every card in sysfs is sampled and the one whose median power is highest under load is taken."""
 
-    def __init__(self, period=0.01):
+    def __init__(self, period=0.01, card=None):
         import threading
         self.period, self.stop, self.nodes, self.samples = period, threading.Event(), [], []
-        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        for card in ([card] if card else sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))):
             n = {}
             for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
                 for name in ("freq1_input", "power1_average", "power1_input"):
@@ -262,6 +263,51 @@ class PowerLog:
             if best is None or row["power_w"] > best["power_w"]:
                 best = row
         return best
+
+
+def sysfs_card_of(torch, local):
+    """/sys/class/drm/cardN/device of HIP device `local`, by PCI address (a box may list more cards than HIP sees --
+    other tenants' GPUs -- and they may be busy); None when it cannot be told."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+    except Exception:  # noqa: BLE001
+        return None
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if os.path.basename(os.path.realpath(card)).startswith(want):
+            return card
+    return None
+
+
+def device_foreign_load(card):
+    """What else is on THIS process's GPU before it launches anything (its context exists, no kernel has run): the
+    card's gpu_busy_percent (0 - 100: a foreign process computing on the device) and the number of OTHER processes with
+    a compute queue on the same GPU (KFD's per-process queue list; None where it cannot be read).  Scalars for the bench
+    line: a slow driver run on a contended box must be tellable from a regression (VERDICT r5 "weak" 4)."""
+    busy = None
+    if card:
+        try:
+            busy = float(open(os.path.join(card, "gpu_busy_percent")).read())
+        except (OSError, ValueError):
+            pass
+    others = None
+    try:
+        root = "/sys/class/kfd/kfd/proc"
+
+        def gpuids(pid):
+            out = set()
+            for q in glob.glob(os.path.join(root, pid, "queues", "*", "gpuid")):
+                try:
+                    out.add(open(q).read().strip())
+                except OSError:
+                    pass
+            return out
+        mine = gpuids(str(os.getpid()))
+        if mine:
+            others = len([d for d in os.listdir(root) if d.isdigit() and int(d) != os.getpid() and gpuids(d) & mine])
+    except OSError:
+        pass
+    return busy, others
 
 
 def free_port() -> int:
@@ -388,6 +434,11 @@ def run_rank(args, rank, world, local, sync, launch):
 
     torch.cuda.set_device(local)  # (per thread: the --threads ranks each select their own)
     dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)    # (the context and its queues exist; nothing of the workload has run)
+    torch.cuda.synchronize(dev)
+    my_card = sysfs_card_of(torch, local)
+    time.sleep(0.05)
+    foreign_busy, foreign_procs = device_foreign_load(my_card) if rank == 0 else (None, None)
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     t_dtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -484,17 +535,22 @@ def run_rank(args, rank, world, local, sync, launch):
         # socket power and shader clock over a loaded window of the SAME launch (>= 2.5 s; hwmon, 10 ms
         # samples, the first fifth dropped): the headline kernel runs at the package power cap, and the
         # clock it is held at belongs next to the roofline fraction
-        with PowerLog() as plog:
+        proc.set_profiling(True)
+        proc.kernel_time(reset=True)
+        with PowerLog(card=my_card) as plog:
             t_pw, n_pw = time.perf_counter(), 0
             while time.perf_counter() - t_pw < args.power_window:
                 for _ in range(20):
                     proc.process_batch(d_in, d_out, frames_per_line, stream=stream)
                 torch.cuda.synchronize(dev)
                 n_pw += 20
+        pw_ms, pw_n = proc.kernel_time(reset=True)
+        proc.set_profiling(False)
         power = plog.summary()
         if power:
             power["window_s"] = round(time.perf_counter() - t_pw, 2)
             power["launches"] = n_pw
+            power["avg_kernel_ms"] = round(pw_ms / max(pw_n, 1), 5)  # the same launch over the whole loaded window
     elapsed = sync.max(elapsed)
     total_samples_per_step = int(sync.sum(n_elems)) if world > 1 else n_elems
 
@@ -594,6 +650,14 @@ def run_rank(args, rank, world, local, sync, launch):
 
     if power:
         result["roofline"]["power"] = power  # medians over the loaded window: the clock the fraction was reached at
+        # ... and as SCALARS (a parser that keeps scalars only must still see them): the state of the box next to the
+        # fraction -- a throttled or contended box and a regression of the kernel look the same in `frac` alone
+        result["roofline"]["sclk_mhz"] = power.get("sclk_mhz")
+        result["roofline"]["power_w"] = power.get("power_w")
+        result["roofline"]["steady_kernel_ms"] = power.get("avg_kernel_ms")
+    result["roofline"]["host_gap_ms_per_step"] = round(ms_per_step - avg_kernel_s * 1e3, 4)
+    result["roofline"]["gpu_busy_other"] = foreign_busy            # gpu_busy_percent before this process launched anything
+    result["roofline"]["other_gpu_processes"] = foreign_procs      # other pids with a KFD context at that moment
 
     # What the relaxed contract means in numbers: the headline's form against the bit-exact form
     # on the first 512 buffers (4 M samples, both from silence) -- after the timed region, nothing of it is timed.
@@ -616,6 +680,62 @@ def run_rank(args, rank, world, local, sync, launch):
         ps["kernel"] = rel_kernel
         result["roofline"]["parity_stats"] = ps
         del w_rel, w_ex
+
+    # ---- the headline's workload on FLOAT64 buffers: what a Go pipe carries (pipe.go:394,437) ---------------------
+    # Every stage output of the reference is allocator.Float64().  Without an opt-in such a batch takes the ordered sum
+    # (bit for bit the oracle's: `bit_exact_form_f64` below, 2 N flops a sample on the float64 matrix pipe); with
+    # PIPE_HIP_PARAM_RELAXED_F64 (hip.Options{RelaxedFloat64}) it takes the same overlap-save kernel as the headline
+    # with 8-byte loads and stores: 16 algorithmic bytes a sample.  Reported beside the headline, never as `value`.
+    if rank == 0 and world == 1 and cfg == 1 and args.dtype == "f32" and not args.no_secondary:
+        Kd = K
+        nd = frames_per_line * C
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        while Kd > 512 and 2 * Kd * F * C * 8 > 0.6 * free_b:
+            Kd //= 2
+        nd = Kd * F * C
+        x64 = torch.empty(nd, dtype=torch.float64, device=dev)
+        y64 = torch.empty(nd, dtype=torch.float64, device=dev)
+        P.synth_fill(x64, synth.line_seed(my_lines[0]))
+        taps64 = synth.fir_lowpass_taps(N)
+        with P.Fir(taps64, F, C, dtype=np.float64, device=local, lines=1, max_batch=Kd) as f64p:
+            f64p.start()
+            _, ekms, en64, ekn = timed(f64p, 3, 1, x64, y64, Kd * F)      # default: the ordered form
+            ex_ms64 = ekms / max(en64, 1)
+            f64p.set_relaxed_f64(True)
+            f64p.start()
+            el64, k64, n64, kn64 = timed(f64p, max(5, args.steps // 4), 3, x64, y64, Kd * F)
+            ms64 = k64 / max(n64, 1)
+            # distance from the ordered form on the first 512 buffers, in units of 2^-53 ||h||_1 max|x| (the header's
+            # bound is 64 of them)
+            n_w = min(nd, 512 * F * C)
+            w_rel = torch.empty(n_w, dtype=torch.float64, device=dev)
+            w_ex = torch.empty(n_w, dtype=torch.float64, device=dev)
+            f64p.start()
+            f64p.process_batch(x64[:n_w], w_rel, n_w // C, stream=stream)
+            f64p.set_exact(True)
+            f64p.start()
+            f64p.process_batch(x64[:n_w], w_ex, n_w // C, stream=stream)
+            exk = f64p.kernel_name()
+            torch.cuda.synchronize(dev)
+            unit = 2.0 ** -53 * float(np.abs(taps64).sum()) * float(x64[:n_w].abs().max().item())
+            err64 = float((w_rel - w_ex).abs().max().item()) / unit
+            del w_rel, w_ex
+        result["headline_f64_buffers"] = {
+            "workload": f"the headline's workload on float64 buffers: 1 Line x {C} ch x {Kd} buffers of {F} frames, {N}-tap FIR, "
+                        "PIPE_HIP_PARAM_RELAXED_F64 set (hip.Options{RelaxedFloat64: true})",
+            "kernel": kn64, "avg_kernel_ms": round(ms64, 5), "launches": n64,
+            "msamples_per_s": round(nd / (ms64 * 1e-3) / 1e6, 1),
+            "algorithmic_bytes_per_launch": nd * 16,
+            "roofline_frac": round(nd * 16 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "max_err_vs_ordered_form_in_2^-53_h1_xmax": round(err64, 3), "bound_in_the_same_unit": 64,
+            "against": f"{exk} (PIPE_HIP_PARAM_EXACT) on the first {n_w} samples",
+            "bit_exact_form_f64": {"kernel": ekn, "avg_kernel_ms": round(ex_ms64, 5),
+                                   "msamples_per_s": round(nd / (ex_ms64 * 1e-3) / 1e6, 1),
+                                   "note": "the default for float64 buffers: no opt-in, bit for bit the oracle's"},
+            "speedup_over_the_ordered_form": round(ex_ms64 / ms64, 2),
+        }
+        del x64, y64
 
     # ---- the other BASELINE configs next to the headline (N = 1, config 1 only) ----------------------------
     # Every "fraction of HBM" below is a STREAMING figure: the timed launches rotate through distinct
@@ -886,6 +1006,8 @@ def run_rank(args, rank, world, local, sync, launch):
             want["c4_chain"] = (PMC_KERNELS["c4_chain"], result["c4_chain"]["algorithmic_bytes_per_launch"])
         if "c5_resampler_mix" in result:
             want["c5_resampler"] = (PMC_KERNELS["c5_resampler"], result["c5_resampler_mix"]["resampler"]["algorithmic_bytes_per_launch"])
+        if "headline_f64_buffers" in result:
+            want["headline_f64"] = (PMC_KERNELS["headline_f64"], result["headline_f64_buffers"]["algorithmic_bytes_per_launch"])
         if "biquad_alone" in result:  # (both shapes run this kernel over the same byte count)
             want["biquad_alone"] = (PMC_KERNELS["biquad_alone"], result["biquad_alone"]["lines_512x8"]["algorithmic_bytes_per_launch"])
         t_pmc = time.perf_counter()
@@ -900,6 +1022,8 @@ def run_rank(args, rank, world, local, sync, launch):
         if live.get("c5_resampler"):
             result["c5_resampler_mix"]["resampler"]["traffic"] = live["c5_resampler"]
             result["c5_resampler_mix"]["resampler"]["traffic_source"] = src_live
+        if live.get("headline_f64"):
+            result["headline_f64_buffers"]["traffic"], result["headline_f64_buffers"]["traffic_source"] = live["headline_f64"], src_live
         if live.get("biquad_alone"):
             result["biquad_alone"]["traffic"] = live["biquad_alone"]  # mean over the two shapes' launches
             result["biquad_alone"]["traffic_source"] = src_live

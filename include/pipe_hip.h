@@ -140,7 +140,17 @@ typedef enum pipe_hip_param {
                                   tests/test_gpu_biquad_seg.py) -- nine decimal orders below a float32 ulp.
                                   PIPE_HIP_PARAM_EXACT wins over it.  Calls of fewer than 1024 frames, cascades
                                   of more than two sections per tile pass and unstable sections keep the
-                                  ordered form as for float32. */
+                                  ordered form as for float32.
+                                  On a FIR (round 6) the same opt-in lets float64 buffers of LARGE calls -- the
+                                  sizes at which float32 buffers take it -- use the overlap-save form: the
+                                  transform is float64 either way, only the widths of loads and stores differ,
+                                  and a float64 batch runs at the rate HBM allows 16 bytes a sample instead of
+                                  the ordered sum's 2 N flops a sample.  Price: |y - oracle| <= 64 * 2^-53 *
+                                  ||h||_1 * max|x| (tested, tests/test_gpu_fir_ols.py; measured: below 4 * 2^-53
+                                  of it) -- the transform's rounding noise, 29 bits below a float32 ulp of the
+                                  filter's full-scale output -- instead of bit for bit.  Per-buffer calls keep
+                                  the ordered form (they are latency-bound).  A chain hands the parameter to all
+                                  of its stages. */
     PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
                                   biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
                                   up after limit_us -- the failure a preempted predecessor tile causes.  A

@@ -51,9 +51,11 @@ type Options struct {
 	// a biquad buffer costs 27 us instead of 100 (the ordered float64 recurrence is one wave's issue).  Default
 	// false: float64 buffers, bit for bit the oracle's float64 chain.
 	Float32 bool
-	// RelaxedFloat64: float64 buffers (the pipe's own: pipe.go:394,437) may take the biquad's tile form
-	// (PIPE_HIP_PARAM_RELAXED_F64): per 4096 x 2 call 22 us instead of 95, results within 256 kappa 2^-53 of the
-	// Line's full scale of the ordered recurrence's instead of bit for bit.  Off by default.
+	// RelaxedFloat64: float64 buffers (the pipe's own: pipe.go:394,437) may take the forms that reassociate float64
+	// arithmetic (PIPE_HIP_PARAM_RELAXED_F64): the biquad's tile form -- per 4096 x 2 call 22 us instead of 95, results
+	// within 256 kappa 2^-53 of the Line's full scale of the ordered recurrence's instead of bit for bit -- and, for
+	// batches (hip.Batch / BatchedChain), the FIR's overlap-save form -- results within 64 * 2^-53 * ||h||_1 * max|x| of
+	// the ordered sum's, several times the ordered form's rate.  Off by default.
 	RelaxedFloat64 bool
 }
 
@@ -176,7 +178,7 @@ func (s *Stage) Allocator() pipe.ProcessorAllocatorFunc {
 		runtime.SetFinalizer(s, (*Stage).Close) // Go has no destructor hook on a Processor
 		if s.opts.RelaxedFloat64 && !s.opts.Float32 {
 			one := C.double(1)
-			// (a stage without a biquad in it answers PIPE_HIP_EINVAL: nothing to relax)
+			// (a stage with neither a FIR nor a biquad in it answers PIPE_HIP_EINVAL: nothing to relax)
 			C.pipe_hip_set_param(p, C.PIPE_HIP_PARAM_RELAXED_F64, &one, 1)
 		}
 		if s.opts.Float32 {

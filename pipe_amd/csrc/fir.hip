@@ -527,6 +527,10 @@ public:
             exact_ = values[0] != 0.0;
             return PIPE_HIP_OK;
         }
+        if (param == PIPE_HIP_PARAM_RELAXED_F64 && count == 1 && values) {  // float64 results may take the overlap-save form too
+            relaxed_f64_ = values[0] != 0.0;
+            return PIPE_HIP_OK;
+        }
         if (param != PIPE_HIP_PARAM_TAPS || count != N_ || !values)
             return PIPE_HIP_EINVAL;
         // Double-buffered on the device: launches already queued keep reading the old copy, the
@@ -580,7 +584,7 @@ public:
         // oracle); float64 output, small calls and exact mode keep the ordered-fma
         // direct form (bit-exact).
         // (a run that is queued behind a doorbell keeps to the direct form: nothing in it allocates or synchronises)
-        if (ols_ && !exact_ && !queued_run && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out) &&
+        if (ols_ && !exact_ && !queued_run && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out || relaxed_f64_) &&
             ols_->items(frames, cfg.channels, nl) >= ols_min_items() &&
             (!ols_->partitioned() || (reinterpret_cast<uintptr_t>(d_in) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(in_dtype)) == 0 &&
                                        reinterpret_cast<uintptr_t>(d_out) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(out_dtype)) == 0))) {
@@ -880,6 +884,7 @@ private:
     int cur_taps_ = 0, cur_hist_ = 0;
     bool hist_f32_ = false;  // the history is in the fused chain kernel's float32 layout
     bool exact_ = std::getenv("PIPE_HIP_FIR_EXACT") != nullptr;
+    bool relaxed_f64_ = false;  // PIPE_HIP_PARAM_RELAXED_F64: float64 buffers (pipe.go:394,437) may take the overlap-save form
     std::unique_ptr<ols::Plan> ols_;
 };
 

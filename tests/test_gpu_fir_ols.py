@@ -419,3 +419,89 @@ def test_mono_lines_ride_two_tiles_per_transform(calls, ntaps, monkeypatch):
         dd = ulp_diff_f32(got[l], want, floor)
         assert dd.max() <= 1.0, f"line {l}: {dd.max()} ulp at {np.unravel_index(dd.argmax(), dd.shape)}"
         assert np.mean(got[l] != want.astype(np.float32)) < 1e-3
+
+
+# ---- float64 buffers: what a Go pipe carries (pipe.go:394,437) -------------------------------------------------------
+def f64_bound(taps, xmax=1.0):
+    """include/pipe_hip.h, PIPE_HIP_PARAM_RELAXED_F64 on a FIR: |y - oracle| <= 64 * 2^-53 * ||h||_1 * max|x|."""
+    return 64.0 * 2.0 ** -53 * float(np.abs(taps).sum()) * xmax
+
+
+def run_batch_f64(taps, x, F, K, lines, relaxed, exact=False):
+    C = x.shape[-1]
+    with P.Fir(taps, F, C, dtype=np.float64, lines=lines, max_batch=K) as p:
+        p.start()
+        if relaxed:
+            p.set_relaxed_f64(True)
+        if exact:
+            p.set_exact(True)
+        d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        outs, names = [], []
+        half = (K // 2) * F
+        frames = x.shape[-2]
+        for a, b in ((0, half), (half, frames)):   # two launches: the history carries in float64
+            xin = d_in[..., a:b, :].contiguous()
+            yout = torch.full_like(xin, float("nan"))
+            p.process_batch(xin, yout, b - a)
+            torch.cuda.synchronize()
+            names.append(p.kernel_name())
+            outs.append(yout)
+        return torch.cat(outs, dim=-2).cpu().numpy(), names
+
+
+@pytest.mark.parametrize("channels,ntaps", [(2, 256), (2, 64), (4, 511), (3, 256), (1, 128), (2, 1100), (1, 2100)])
+def test_float64_buffers_take_the_overlap_save_form_only_when_asked(channels, ntaps, monkeypatch):
+    """Without PIPE_HIP_PARAM_RELAXED_F64 a float64 batch is the ordered sum, bit for bit the oracle's; with it the same
+    batch takes the overlap-save kernel (float64 loads and stores around the same float64 transform) and stays within
+    the bound the header states; PIPE_HIP_PARAM_EXACT wins over the opt-in."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    F, K, lines = 1024, 24, 2
+    taps = synth.fir_lowpass_taps(ntaps, fc=0.11)   # float64 taps, not rounded to float32: a float64 host's own
+    x = np.stack([synth.samples(synth.line_seed(700 + l), 0, K * F * channels, np.float64).reshape(K * F, channels)
+                  for l in range(lines)])
+    want = np.stack([O.Fir(taps, channels).process(x[l]).reshape(K * F, channels) for l in range(lines)])
+    plain, names = run_batch_f64(taps, x, F, K, lines, relaxed=False)
+    assert all("fir_mfma_kernel<f64,f64>" in n or "fir_direct_kernel<f64,f64>" in n for n in names), names
+    assert np.array_equal(plain, want)
+    got, names = run_batch_f64(taps, x, F, K, lines, relaxed=True)
+    assert all(n.startswith("fir_ols_kernel<f64,f64,32x32") for n in names), names
+    assert all(("partitioned" in n) == (ntaps > 512) for n in names), names
+    err = np.abs(got - want).max()
+    assert err <= f64_bound(taps), (err, f64_bound(taps), err / (2.0 ** -53 * np.abs(taps).sum()))
+    assert not np.array_equal(got, want) or ntaps < 32   # (it IS another arithmetic: the bound is not vacuous)
+    pinned, names = run_batch_f64(taps, x, F, K, lines, relaxed=True, exact=True)
+    assert all("fir_ols_kernel" not in n for n in names), names
+    assert np.array_equal(pinned, want)
+
+
+def test_float64_chain_staged_with_the_relaxed_forms(monkeypatch):
+    """FIR -> biquad -> gain on float64 buffers with PIPE_HIP_PARAM_RELAXED_F64 on the chain: the FIR's overlap-save form
+    with float64 results, the biquad's tile form, the gain folded into its store -- against the oracle's chain within the
+    sum of the two stages' bounds (the biquad's low-pass gain is <= 1: the FIR's error passes through it unamplified up
+    to kappa)."""
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    lines, C, F = 6, 2, 4096 * 6
+    taps = synth.fir_lowpass_taps(256)
+    q = synth.biquad_rbj_lowpass()
+    g = 0.7071067811865476
+    x = np.stack([synth.samples(synth.line_seed(720 + l), 0, F * C, np.float64).reshape(F, C) for l in range(lines)])
+    kw = dict(dtype=np.float64, lines=lines, max_batch=6)
+    res = {}
+    for relaxed in (False, True):
+        with P.Chain([P.Fir(taps, 4096, C, **kw), P.Biquad(q, 4096, C, **kw), P.Gain(g, 4096, C, **kw)]) as p:
+            p.start()
+            if relaxed:
+                p.set_relaxed_f64(True)
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.full_like(d_in, float("nan"))
+            p.process_batch(d_in, d_out, F)
+            torch.cuda.synchronize()
+            res[relaxed] = (d_out.cpu().numpy(), p.kernel_name())
+    want = np.stack([O.gain(O.Biquad(q, C).process(O.Fir(taps, C).process(x[l])), g).reshape(F, C) for l in range(lines)])
+    assert np.array_equal(res[False][0], want), res[False][1]            # default: bit for bit
+    assert "fir_ols_kernel<f64,f64" in res[True][1], res[True][1]
+    from tests import _tol
+    kap = _tol.kappa(q)
+    bound = (256.0 * kap * 2.0 ** -53) * np.abs(want).max() + kap * f64_bound(taps)
+    err = np.abs(res[True][0] - want).max()
+    assert err <= bound, (err, bound)
