@@ -883,6 +883,33 @@ def run_rank(args, rank, world, local, sync, launch):
                             f"{K5} buffers of {F} frames per launch; 2-input mix of the same stream",
                 "resampler": r5,
             }
+        # the same Line at the HEADLINE's stream length (the 1024-buffer launch above is 28 us, a third of it edges: the
+        # first blocks' loads and the last blocks' stores; the headline takes 131 072 buffers a launch): steady state
+        Ks = min(K, d_src.numel() // (F * C))
+        n_ins = Ks * F
+        caps = -(-n_ins * up5 // down5) + 1
+        try:
+            out_s = torch.empty(caps * C, dtype=t_dtype, device=dev)
+        except RuntimeError:
+            out_s = None
+        if out_s is not None and Ks >= 8 * K5:
+            with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C, dtype=np_dtype, device=local,
+                             max_batch=Ks) as rss:
+                rss.start()
+                gots = [0]
+
+                def rss_call():
+                    gots[0] = rss.resample_batch(d_src[:n_ins * C], n_ins, out_s, caps, stream=stream)
+                _, kss, nss, knss = timed(rss, 10, 3, None, None, 0, call=[rss_call])
+                mss = kss / max(nss, 1)
+                bys = (n_ins + gots[0]) * C * 4
+                c5["resampler_steady_state"] = {
+                    "workload": f"the same Line, {Ks} buffers of {F} frames per launch (the headline's stream length; streaming by its size)",
+                    "kernel": knss, "avg_kernel_ms": round(mss, 5), "algorithmic_bytes_per_launch": bys,
+                    "in_frames": n_ins, "out_frames": gots[0],
+                    "roofline_frac": round(bys / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "msamples_out_per_s": round(gots[0] * C / (mss * 1e-3) / 1e6, 1)}
+            del out_s
         # 64 such Lines in one launch (one Line x 32 us does not fill the chip)
         L5 = 64
         with P.Resampler(synth.resampler_proto(up5, down5, T5), T5, up5, down5, F, C, dtype=np_dtype, device=local,

@@ -318,7 +318,8 @@ struct BiquadTilePowers {
 // Segment g's start state is then its zero-start scan value + A^g s, A^g from a table.
 struct BiquadLookArgs {
     unsigned long long *aggr, *incl;  // [T][nseries][2 S] doubles as two tagged words each
-    unsigned *ticket, *ticket_next;   // [nl] tiles started per Line: this launch's counters, the next launch's
+    unsigned *ticket, *ticket_next;   // [nl][8] tiles started per (Line, class): this launch's counters, the next launch's
+    int classes;                      // counters per Line in use: 1, or 8 / nl (few Lines: one counter per XCD -- see the kernel)
     const double *tab;                // [256][2 S][2 S]: A^g
     int *err;                         // host-visible: a look-back that gave up
     unsigned epoch;
@@ -405,13 +406,22 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
         } else {
             // a counter per Line (one counter for the launch: thousands of device-scope atomics on one address,
             // 17 of 47 us); this launch's counters count up from zero, the tile that draws 0 clears the Line's
-            // counter of the NEXT launch (the two sets alternate)
+            // counter of the NEXT launch (the two sets alternate).
+            // FEW Lines (1, 2, 4: ONE stereo Line of 2048 buffers is 2048 draws from one address again, round 5:
+            // 0.35 of HBM against 0.44 for 512 Lines): R = 8 / nl counters per Line.  Workgroup b is the k-th of its
+            // Line (k = b / nl) and belongs to class j = k % R, the tiles t = j (mod R) of the Line; it draws its
+            // class's next number q and takes tile q R + j.  Class (Line l, j) is exactly the workgroups with
+            // b % 8 == j nl + l -- ONE XCD's (block b runs on XCD b % 8) -- and holds as many workgroups as tiles.
+            // No residency condition, as before: the lowest unfinished tile of the launch has drawn its number (the
+            // numbers of a class are drawn in starting order, the lower ones are finished, and an XCD whose
+            // workgroups have finished starts its next one, which draws it) and all its predecessors are finished.
             line = (int)(blockIdx.x % (unsigned)lk.nl);
+            const int R = lk.classes, cls = R > 1 ? (int)((blockIdx.x / (unsigned)lk.nl) % (unsigned)R) : 0;
             if (tid == 0) {
-                const int t = (int)__hip_atomic_fetch_add(lk.ticket + line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int t = (int)__hip_atomic_fetch_add(lk.ticket + line * 8 + cls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (t == 0)
-                    lk.ticket_next[line] = 0u;
-                *reinterpret_cast<int *>(yb) = t;
+                    lk.ticket_next[line * 8 + cls] = 0u;
+                *reinterpret_cast<int *>(yb) = t * R + cls;
             }
             __syncthreads();
             tile = *reinterpret_cast<volatile int *>(yb);
@@ -2049,13 +2059,16 @@ public:
         }
         // two sets of per-Line counters, used in turn; a launch over other Lines than the last one starts from
         // cleared sets (the tile that clears a Line's next counter only runs in launches that cover the Line)
-        const size_t tick_bytes = sizeof(unsigned) * 2u * (size_t)cfg.lines;
-        if (!ticket_.p || tick_first_ != win_first || tick_nl_ != nl) {
+        const size_t tick_bytes = sizeof(unsigned) * 2u * 8u * (size_t)cfg.lines;
+        // (1, 2 or 4 Lines of many tiles: a counter per XCD and Line -- biquad_tile_kernel)
+        const int classes = (nl == 1 || nl == 2 || nl == 4) && a.T >= 64 ? 8 / nl : 1;
+        if (!ticket_.p || tick_first_ != win_first || tick_nl_ != nl || tick_classes_ != classes) {
             if (!ticket_.p)
                 PH_TRY(ticket_.alloc(tick_bytes));
             PH_HIP(hipMemsetAsync(ticket_.p, 0, tick_bytes, s));
             tick_first_ = win_first;
             tick_nl_ = nl;
+            tick_classes_ = classes;
         }
         if (a.T > 1)  // (a launch of one-tile Lines draws no numbers and clears nothing)
             tick_set_ ^= 1;
@@ -2091,8 +2104,9 @@ public:
             e = ++epochs;
         lk->aggr = static_cast<unsigned long long *>(look_.p);
         lk->incl = lk->aggr + words;
-        lk->ticket = static_cast<unsigned *>(ticket_.p) + (size_t)tick_set_ * cfg.lines + win_first;
-        lk->ticket_next = static_cast<unsigned *>(ticket_.p) + (size_t)(tick_set_ ^ 1) * cfg.lines + win_first;
+        lk->ticket = static_cast<unsigned *>(ticket_.p) + ((size_t)tick_set_ * cfg.lines + win_first) * 8u;
+        lk->ticket_next = static_cast<unsigned *>(ticket_.p) + ((size_t)(tick_set_ ^ 1) * cfg.lines + win_first) * 8u;
+        lk->classes = classes;
         lk->tab = static_cast<const double *>(tab_.p);
         lk->err = err_dev_;
         lk->epoch = e;
@@ -2226,7 +2240,7 @@ private:
     PinnedBuf err_;
     int *err_dev_ = nullptr;
     bool err_checked_ = true;
-    int tick_set_ = 0, tick_first_ = -1, tick_nl_ = -1;
+    int tick_set_ = 0, tick_first_ = -1, tick_nl_ = -1, tick_classes_ = -1;
     std::vector<double> tab_host_;
     int tab_seg_ = -1;
     BiquadScanPowers sp_{};

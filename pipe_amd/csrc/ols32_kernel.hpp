@@ -16,6 +16,9 @@ namespace pipehip {
 namespace ols {
 
 constexpr int kWaves32 = 8;             // waves per workgroup = per CU
+#ifndef PH_FUSE_ABLATE
+#define PH_FUSE_ABLATE 0
+#endif
 
 // -DPH_FUSE_PROF: per-phase s_memtime sums of every wave of the fused kernel (a debug build of
 // the library, scripts/build_prof_lib.sh; never the shipped one)
@@ -690,11 +693,37 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
 #pragma unroll
         for (int c = 0; c < 32; ++c)
             xi[c] = PH_ROW(c);
+#if PH_FUSE_ABLATE == 1 || PH_FUSE_ABLATE == 2 || PH_FUSE_ABLATE == 3
+        // ablation builds (scripts/build_ablate_lib.sh chain_fused PH_FUSE_ABLATE fab 1 2 3; WRONG results): what pass 5 would
+        // cost with the numerator and the gain folded into the tap spectrum (1: three operations a sample), the numerator
+        // alone (2: four), the gain alone (3: five)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+#if PH_FUSE_ABLATE == 3
+            xr[c] = biquad_step<S>(xr[c], str, fc);
+            xi[c] = biquad_step<S>(xi[c], sti, fc);
+#else
+            {
+                const double y = xr[c] + str[0];
+                str[0] = __builtin_fma(-fc.c[0][3], y, str[1]);
+                str[1] = -fc.c[0][4] * y;
+                xr[c] = PH_FUSE_ABLATE == 2 ? y * fc.gain : y;
+            }
+            {
+                const double y = xi[c] + sti[0];
+                sti[0] = __builtin_fma(-fc.c[0][3], y, sti[1]);
+                sti[1] = -fc.c[0][4] * y;
+                xi[c] = PH_FUSE_ABLATE == 2 ? y * fc.gain : y;
+            }
+#endif
+        }
+#else
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
             xr[c] = biquad_step<S>(xr[c], str, fc) * fc.gain;
             xi[c] = biquad_step<S>(xi[c], sti, fc) * fc.gain;
         }
+#endif
         if (ends_here && on_boundary) {
             unsigned long long *dst = own_write_slot<NV>(fa.own + series * (2 * 2 * NV), fa.epoch);
 #pragma unroll

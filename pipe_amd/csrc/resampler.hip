@@ -732,7 +732,7 @@ struct WaveArgs {
     int lead;       // virtual outputs ahead of the call's first one: groups start where the phase is 0
     int groups_per_line;
     int64_t nb;     // input frame (relative to this call) the first virtual output reads
-    int small_in;   // a Line's input is below 2 GiB: its frames are addressed through one raw buffer
+    int small_in;   // (unused since round 6: a step's raw buffer begins at its window, so a Line may be of any length)
     const double *ptaps;  // [G][2 T + 1][64]
     unsigned long long *prof;  // PH_RS_PROF builds: [wave][5] s_memtime ticks per phase
 };
@@ -778,7 +778,8 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
     // (plain scalars, not a struct: a struct carried around the loop went through 20 bytes of scratch per lane)
     //   line, odd;  m0: the wave's first output, relative to the call's first (negative: virtual outputs);
     //   base_e: the window's first staged frame, relative to the call's input (even);
-    //   interior: the window starts inside the call's input -- staged by raw buffer loads, no per-lane tests;
+    //   interior: the window starts inside the call's input -- staged by raw buffer loads, no per-lane tests (a Line of
+    //             any length: the step's buffer begins at the window's first frame);
     //   full: every output of the wave belongs to the call -- one 16-byte store per lane, no per-lane tests
 #define PH_RW_STEP(P, GID)                                                                            \
     do {                                                                                              \
@@ -788,7 +789,7 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
         const int64_t base_ = t.nb + (int64_t)g_ * t.adv + (int64_t)nA0 - H - kPairPad;              \
         P##base_e = base_ & ~(int64_t)1; /* even: 16-byte pieces of the input, 16-byte plane cells */ \
         P##odd = (int)(base_ - P##base_e);                                                            \
-        P##interior = P##base_e >= 0 && t.small_in != 0;                                              \
+        P##interior = P##base_e >= 0;                                                                 \
         P##full = P##m0 >= 0 && P##m0 + 128 <= a.out_frames;                                          \
     } while (0)
     int cs_line, cs_odd, ns_line = 0, ns_odd = 0;

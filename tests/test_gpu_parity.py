@@ -495,6 +495,41 @@ def test_resample_batch_at_the_bench_shape_windows_against_oracle():
     assert np.array_equal(mo.cpu().numpy().reshape(m, C), wm)
 
 
+def test_resample_batch_of_a_line_longer_than_2_gib_windows_against_oracle():
+    """A stereo float32 Line of 70 000 pipe buffers (2.3 GB in, 2.5 GB out) in ONE call: beyond the 2^31 bytes a raw
+    buffer's record count can name.  Since round 6 every step of the wave kernel makes its buffer at its own window (the
+    window's start is no longer an unchecked scalar offset into one buffer over the whole Line), so such a Line keeps the
+    fast staging path.  An output depends on T input frames and nothing else: windows of the result -- the first frames,
+    the frames around the 2 GiB mark of the input, the last frames -- against an oracle started on a period boundary."""
+    T, up, down, F, C, K = 24, 160, 147, 4096, 2, 70000
+    proto = synth.resampler_proto(up, down, T)
+    n_in = K * F
+    assert n_in * C * 4 > (1 << 31)
+    cap = -(-n_in * up // down) + 1
+    d_in = torch.empty(n_in * C, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(3))
+    d_out = torch.full((cap * C,), float("nan"), dtype=torch.float32, device="cuda")
+    with P.Resampler(proto, T, up, down, F, C, dtype=np.float32, max_batch=K) as p:
+        p.start()
+        n_out = p.resample_batch(d_in, n_in, d_out, cap)
+        torch.cuda.synchronize()
+        assert p.kernel_name().startswith("resample_wave_kernel"), p.kernel_name()
+    assert n_out == -(-n_in * up // down)
+    assert not torch.isnan(d_out[: n_out * C]).any().item()   # every output frame was written
+    W = 40000   # input frames per window
+    mark = (1 << 31) // (C * 4)
+    for f_start in (0, mark - W // 2, n_in - W):
+        j = f_start // down            # the window begins on a period boundary: phase 0, output index j * up
+        f0 = j * down
+        n = min(W, n_in - f0)
+        x = synth.samples(synth.line_seed(3), f0 * C, n * C).reshape(n, C)
+        want = O.Resampler(proto, T, up, down, C).process(x).reshape(-1, C).astype(np.float32)
+        skip = 0 if f0 == 0 else -(-T * up // down) + 1     # outputs whose window reaches before f0 (silence for the oracle)
+        m0 = j * up
+        got = d_out[(m0 + skip) * C:(m0 + want.shape[0]) * C].cpu().numpy().reshape(-1, C)
+        assert np.array_equal(got, want[skip:]), f_start
+
+
 # ------------------------------------------------------------------ mix, chain
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n_in", [2, 3])
