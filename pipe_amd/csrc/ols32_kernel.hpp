@@ -480,6 +480,9 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
             const int gp = gi - (l5 + 1) * a.pairs;  // predecessor t - 1 - l5 of this pair
             const LocalRec<NV> *r = ring + (gp & (kLocalRing - 1));
             const unsigned long long want = (unsigned long long)(gp / kLocalRing + 1);
+#if PH_FUSE_ABLATE == 5  // (5: the predecessors' records are taken as they are, nobody waits)
+            ready = true;
+#endif
             while (!__all(ready)) {
                 if (!ready) {
                     if (__hip_atomic_load(&r->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want) {
@@ -694,7 +697,8 @@ __device__ __forceinline__ void fused_epilogue(cd (&lo)[16], cd (&hi)[16], doubl
         for (int c = 0; c < 32; ++c)
             xi[c] = PH_ROW(c);
 #if PH_FUSE_ABLATE == 1 || PH_FUSE_ABLATE == 2 || PH_FUSE_ABLATE == 3
-        // ablation builds (scripts/build_ablate_lib.sh chain_fused PH_FUSE_ABLATE fab 1 2 3; WRONG results): what pass 5 would
+        // ablation builds (scripts/build_ablate_lib.sh chain_fused PH_FUSE_ABLATE fab 1 2 3 4 5 7 8; WRONG results;
+        // profiles/r06_chain_fold_ab.txt, r06_chain_ablation.txt): what pass 5 would
         // cost with the numerator and the gain folded into the tap spectrum (1: three operations a sample), the numerator
         // alone (2: four), the gain alone (3: five)
 #pragma unroll
@@ -1220,7 +1224,11 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             const TIn *base = in_base + (int64_t)line * a.line_stride + fr00 * a.C;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<TIn *>(base), 0, bytes31((a.frames - fr00) * a.C * (int64_t)sizeof(TIn)), 0x00020000);
+#if PH_FUSE_ABLATE == 8  // (8: no window is fetched -- every load lands beyond the buffer and reads zero)
+            const unsigned v0 = kOut32;
+#else
             const unsigned v0 = valid ? (unsigned)((((tile - tile0) * a.L + l5) * a.C + c0) * (int)sizeof(TIn)) : kOut32;
+#endif
             In2 pf[32];
             if constexpr (MONO) {
                 const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
@@ -1328,12 +1336,14 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
             __builtin_amdgcn_s_setprio(3);
             __builtin_amdgcn_sched_barrier(0);  // the epilogue's early loads stay out of the transform's registers
             // (LOCAL: item index in the workgroup's list = two per unit, Lines padded to whole units)
+#if PH_FUSE_ABLATE != 4  // (4: the transform and the stores alone -- what the epilogue costs in all)
             if constexpr (S >= 2)
                 fused_epilogue_sections<S, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
                                                   (int)(2 * unit) + half);
             else
                 fused_epilogue<S, GENERAL, LOCAL>(lo, hi, pa, pb, a, fa, fc, cur_line, tile, c0 >> 1, valid, l5, half, ring,
                                                   (int)(2 * unit) + half PH_FPROF_ARGS);
+#endif
             __builtin_amdgcn_sched_barrier(0);  // ... and the store addresses are not computed ahead of it
             __builtin_amdgcn_s_setprio(0);
             PH_FTIME(3);
@@ -1367,7 +1377,11 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int off = o0 + r * (int)out_step;
+#if PH_FUSE_ABLATE == 7  // (7: nothing is stored -- every store lands beyond the buffer)
+                    buf_store_pair<TOut>(rs, kOut32 | (unsigned)(off & 0xFFFF), PH_NAT(r).re, PH_NAT(r).im);
+#else
                     buf_store_pair<TOut>(rs, i0 + 32 * r >= 0 ? (unsigned)off : kOut32, PH_NAT(r).re, PH_NAT(r).im);
+#endif
                 }
             }
         }
