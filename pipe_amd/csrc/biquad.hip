@@ -604,11 +604,21 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 } else {
                     // tile 0 is asked for its TRUE end state only: it alone reads the series' carried state, and the
                     // Line's last tile overwrites that state once tile 0 has published (no copy after the launch)
+                    // (both records requested together: one round trip, not one after the other -- with ONE Line the
+                    // predecessor is the workgroup that started just ahead of this one, its aggregate is published about
+                    // when it is asked for, and every extra round trip is on the path of all of the Line's tiles)
                     const int64_t sk = ((int64_t)k * a.nseries + series) * (2 * N);
-                    if (look_read<N>(lk.incl + sk, v, lk.epoch))
+                    double va[N];
+                    const bool gi = look_read<N>(lk.incl + sk, v, lk.epoch);
+                    const bool ga = look_read<N>(lk.aggr + sk, va, lk.epoch);
+                    if (gi) {
                         last = got = true;
-                    else if (k > 0 && look_read<N>(lk.aggr + sk, v, lk.epoch))
+                    } else if (k > 0 && ga) {
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            v[i] = va[i];
                         got = true;
+                    }
                 }
                 if (got) {
 #pragma unroll
@@ -645,7 +655,7 @@ biquad_tile_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                     --k;
                     spins = 0;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                     if (look_expired(spins, spin_t0, lk.spin_ticks)) {  // seconds: something is wrong; give up loudly
                         *lk.err = 1;
                         break;
