@@ -150,7 +150,10 @@ typedef enum pipe_hip_param {
                                   of it) -- the transform's rounding noise, 29 bits below a float32 ulp of the
                                   filter's full-scale output -- instead of bit for bit.  Per-buffer calls keep
                                   the ordered form (they are latency-bound).  A chain hands the parameter to all
-                                  of its stages. */
+                                  of its stages -- and a FIR -> biquad (-> gain) chain whose FIR and biquad both
+                                  carry it takes the FUSED kernel on float64 buffers as it does on float32 ones
+                                  (one read and one write of the buffers, 16 bytes a sample); bound as tested
+                                  (tests/test_gpu_chain_fused.py): the sum of the two stages' bounds above. */
     PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
                                   biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
                                   up after limit_us -- the failure a preempted predecessor tile causes.  A

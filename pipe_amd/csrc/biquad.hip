@@ -1867,6 +1867,7 @@ public:
         v->coeffs = &q_.c[0][0];
         v->sections = S_;
         v->relaxed = !exact_ && !env_exact_ && relaxed_ok();
+        v->relaxed_f64 = relaxed_f64_;
         return true;
     }
 

@@ -58,7 +58,10 @@ public:
             BiquadFuseView bv{};
             double g = 1.0;
             const bool has_gain = ns == 3 && gain_value(stages[2].get(), &g);
+            const bool f64 = in_dtype == PIPE_HIP_F64;  // (float64 buffers, pipe.go:394,437: only with PIPE_HIP_PARAM_RELAXED_F64 on both stages)
+            fv.f64_stream = f64;
             if (stages[0]->fuse_view_fir(&fv, s, false) && stages[1]->fuse_view_biquad(&bv) && fv.relaxed && bv.relaxed &&
+                (!f64 || (fv.relaxed_f64 && bv.relaxed_f64)) &&
                 bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
                 const int64_t L = 1024 - (fv.ntaps - 1 + 31) / 32 * 32;
                 const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
@@ -67,7 +70,7 @@ public:
                 if (items >= fv.min_items && fused_->accepts(bv.coeffs, bv.sections, fv.ntaps, frames, s)) {
                     if (!stages[0]->fuse_view_fir(&fv, s, true))  // (history into the fused kernel's layout)
                         return PIPE_HIP_EHIP;
-                    PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, frames, cfg.channels, cfg.lines, s, &timer,
+                    PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, f64, frames, cfg.channels, cfg.lines, s, &timer,
                                        &last_kernel));
                     last_fused_ = FusedCall{d_in, d_out, in_dtype, out_dtype, frames, true};
                     return stages[0]->fuse_commit_fir(s);
@@ -291,14 +294,15 @@ private:
             return false;
         if (stages.size() != 2 && stages.size() != 3)
             return false;
-        if (in_dtype != PIPE_HIP_F32 || out_dtype != PIPE_HIP_F32 || cfg.channels % 2 != 0)
+        if (in_dtype != out_dtype || cfg.channels % 2 != 0)
             return false;
         if (stages.size() == 3) {
             double g;
             if (!gain_value(stages[2].get(), &g))
                 return false;
         }
-        return reinterpret_cast<uintptr_t>(d_in) % 8 == 0 && reinterpret_cast<uintptr_t>(d_out) % 8 == 0;  // (float32 channel pairs)
+        const uintptr_t pair = 2 * dtype_size(in_dtype);  // (channel pairs are one access)
+        return reinterpret_cast<uintptr_t>(d_in) % pair == 0 && reinterpret_cast<uintptr_t>(d_out) % pair == 0;
     }
 
     DevBuf tmp_[2];

@@ -109,9 +109,9 @@ struct TailArgs {
 };
 constexpr int kTailSeries = 8;  // series (half-waves) per workgroup
 typedef const __attribute__((address_space(4))) double *tail_const_f64;
-template <int S>
+template <int S, typename T>
 __global__ void __launch_bounds__(32 * kTailSeries)
-chain_tail_kernel(const float *__restrict__ in_base, const float *__restrict__ hist_base,
+chain_tail_kernel(const T *__restrict__ in_base, const T *__restrict__ hist_base,
                   const double *__restrict__ taps, const TailArgs a, const FuseConst<S> fc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
@@ -128,8 +128,8 @@ chain_tail_kernel(const float *__restrict__ in_base, const float *__restrict__ h
     const int plast = a.HP + len - 1, kl = plast >> 5, jl = plast & 31;
     const int64_t f0 = t0 + 32 * kl - a.HP;  // first frame of the segment
     if (live) {
-        const float *__restrict__ in = in_base + (int64_t)line * a.line_stride + ch;
-        const float *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
+        const T *__restrict__ in = in_base + (int64_t)line * a.line_stride + ch;
+        const T *__restrict__ hist = hist_base + (int64_t)line * a.H * a.C + ch;
         // all loads of a lane first, then the LDS stores: one memory round trip, not one per trip
         constexpr int kMaxTrips = (32 + 511 + 31) / 32;  // taps <= 512
         double v[kMaxTrips];
@@ -401,10 +401,10 @@ static constexpr size_t fused_lds_bytes()
                   : 0);
 }
 
-template <int S, bool GENERAL, bool LOCAL>
+template <typename T, int S, bool GENERAL, bool LOCAL>
 static bool form_fits()
 {
-    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
+    auto kfn = ols::fir_ols32_kernel<T, T, S, GENERAL, LOCAL>;
     const size_t lds = fused_lds_bytes<S, LOCAL>();
     int per_cu = 0;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -429,8 +429,11 @@ bool Plan::launchable()
     dev &= 63;
     std::lock_guard<std::mutex> lock(mu);
     if (!known[dev])
-        known[dev] = form_fits<1, true, false>() && form_fits<1, false, true>() && form_fits<1, false, false>() &&
-                             form_fits<2, false, true>() && form_fits<2, false, false>()
+        known[dev] = form_fits<float, 1, true, false>() && form_fits<float, 1, false, true>() && form_fits<float, 1, false, false>() &&
+                             form_fits<float, 2, false, true>() && form_fits<float, 2, false, false>() &&
+                             form_fits<double, 1, true, false>() && form_fits<double, 1, false, true>() &&
+                             form_fits<double, 1, false, false>() && form_fits<double, 2, false, true>() &&
+                             form_fits<double, 2, false, false>()
                          ? 1
                          : 2;
     return known[dev] == 1;
@@ -481,11 +484,11 @@ void Plan::debug_fail_next(int tile, double limit_us)
     impl_->debug_limit_us = limit_us;
 }
 
-template <int S, bool GENERAL, bool LOCAL>
-static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const void *hist, Args32 a, const FuseArgs &fa,
-                  const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
+template <typename T, int S, bool GENERAL, bool LOCAL>
+static int launch_t(const ols::Plan::Impl &P, const void *d_in, void *d_out, const void *hist, Args32 a, const FuseArgs &fa,
+                    const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
 {
-    auto kfn = ols::fir_ols32_kernel<float, float, S, GENERAL, LOCAL>;
+    auto kfn = ols::fir_ols32_kernel<T, T, S, GENERAL, LOCAL>;
     const size_t lds = fused_lds_bytes<S, LOCAL>();
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -517,8 +520,8 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
         else
             PH_HIP(hipStreamWaitEvent(s, chain_done[dev], 0));
     }
-    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const float *>(d_in),
-                          static_cast<float *>(d_out), static_cast<const float *>(hist), static_cast<const double2 *>(P.tw32.p),
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(kWaves32 * 64), lds, s, ev_a, ev_b, 0, static_cast<const T *>(d_in),
+                          static_cast<T *>(d_out), static_cast<const T *>(hist), static_cast<const double2 *>(P.tw32.p),
                           static_cast<const double2 *>(P.hperm[P.cur].p), a, fa, fc);
     PH_HIP(hipGetLastError());
     if constexpr (!LOCAL)
@@ -587,8 +590,17 @@ static int launch(const ols::Plan::Impl &P, const void *d_in, void *d_out, const
     return PIPE_HIP_OK;
 }
 
+// (the stream's element type: float32, or float64 on a handle switched with PIPE_HIP_PARAM_RELAXED_F64)
+template <int S, bool GENERAL, bool LOCAL>
+static int launch(bool f64, const ols::Plan::Impl &P, const void *d_in, void *d_out, const void *hist, const Args32 &a,
+                  const FuseArgs &fa, const FuseConst<S> &fc, hipStream_t s, KernelTimer *timer)
+{
+    return f64 ? launch_t<double, S, GENERAL, LOCAL>(P, d_in, d_out, hist, a, fa, fc, s, timer)
+               : launch_t<float, S, GENERAL, LOCAL>(P, d_in, d_out, hist, a, fa, fc, s, timer);
+}
+
 int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_processor::BiquadFuseView &bq, bool has_gain,
-              double gain, const void *d_in, void *d_out, int64_t frames, int channels, int lines, hipStream_t s,
+              double gain, const void *d_in, void *d_out, bool f64, int64_t frames, int channels, int lines, hipStream_t s,
               KernelTimer *timer, const char **kernel_name)
 {
     Impl &I = *impl_;
@@ -701,25 +713,25 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         // two sections: the sections one after the other over the tile in segment layout (ols32_kernel.hpp)
         I.c2.D = I.D;
         if (local) {
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain,local>";
-            PH_TRY((launch<2, false, true>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+            *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad2+gain,local>" : "chain_fused_kernel<f32,f32,fir+biquad2+gain,local>";
+            PH_TRY((launch<2, false, true>(f64, P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
         } else {
-            *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
-            PH_TRY((launch<2, false, false>(P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
+            *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad2+gain>" : "chain_fused_kernel<f32,f32,fir+biquad2+gain>";
+            PH_TRY((launch<2, false, false>(f64, P, d_in, d_out, fir.hist, a, fa, I.c2, s, timer)));
         }
     } else
     if (general) {
         I.c1.D = force_general && I.D <= 32 ? I.D : (1 << 30);
-        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
-        PH_TRY((launch<1, true, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad1+gain,general>" : "chain_fused_kernel<f32,f32,fir+biquad1+gain,general>";
+        PH_TRY((launch<1, true, false>(f64, P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     } else if (local) {
         I.c1.D = I.D;
-        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain,local>";
-        PH_TRY((launch<1, false, true>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad1+gain,local>" : "chain_fused_kernel<f32,f32,fir+biquad1+gain,local>";
+        PH_TRY((launch<1, false, true>(f64, P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     } else {
         I.c1.D = I.D;
-        *kernel_name = "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
-        PH_TRY((launch<1, false, false>(P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
+        *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad1+gain>" : "chain_fused_kernel<f32,f32,fir+biquad1+gain>";
+        PH_TRY((launch<1, false, false>(f64, P, d_in, d_out, fir.hist, a, fa, I.c1, s, timer)));
     }
     // the state after every Line's last frame: the fused kernel's own work when the Line ends on a
     // segment boundary (PIPE_HIP_CHAIN_NO_TAIL: debug switch)
@@ -739,11 +751,17 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.epoch = I.epoch;
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
-        if (S == 2)
-            hipLaunchKernelGGL(chain_tail_kernel<2>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+        if (S == 2 && f64)
+            hipLaunchKernelGGL((chain_tail_kernel<2, double>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const double *>(d_in), static_cast<const double *>(fir.hist), fir.taps, ta, I.c2);
+        else if (S == 2)
+            hipLaunchKernelGGL((chain_tail_kernel<2, float>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
                                static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c2);
+        else if (f64)
+            hipLaunchKernelGGL((chain_tail_kernel<1, double>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                               static_cast<const double *>(d_in), static_cast<const double *>(fir.hist), fir.taps, ta, I.c1);
         else
-            hipLaunchKernelGGL(chain_tail_kernel<1>, dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+            hipLaunchKernelGGL((chain_tail_kernel<1, float>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
                                static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c1);
         PH_HIP(hipGetLastError());
     }

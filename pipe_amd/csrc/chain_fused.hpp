@@ -26,9 +26,10 @@ public:
 
     static bool enabled();  // PIPE_HIP_CHAIN_FUSED=0 switches the fused form off
     // One launch: every Line advances by `frames` frames through FIR -> biquad (-> gain).
-    // float32 buffers, even channel count, 16-byte aligned pointers (the caller checks).
+    // float32 buffers -- or float64 ones (`f64`: a handle switched with PIPE_HIP_PARAM_RELAXED_F64) --, an even channel
+    // count, pointers aligned to a channel pair (the caller checks).
     int run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_processor::BiquadFuseView &bq, bool has_gain,
-            double gain, const void *d_in, void *d_out, int64_t frames, int channels, int lines, hipStream_t s,
+            double gain, const void *d_in, void *d_out, bool f64, int64_t frames, int channels, int lines, hipStream_t s,
             KernelTimer *timer, const char **kernel_name);
     // the fused kernel's workgroup (512 threads + its LDS) fits a CU of the current device
     static bool launchable();

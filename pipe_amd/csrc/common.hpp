@@ -349,12 +349,15 @@ struct pipe_hip_processor {
         int ntaps;
         bool relaxed;          // the stage may use a form that is not bit-exact
         int64_t min_items;     // smallest call (in FFT items) that takes the overlap-save form
+        bool f64_stream;       // IN: the chain's buffers are float64 (the history then stays float64)
+        bool relaxed_f64;      // PIPE_HIP_PARAM_RELAXED_F64 is set on the stage: float64 RESULTS may be relaxed too
     };
     struct BiquadFuseView {
         double *state;         // [lines][C][S][2]
         const double *coeffs;  // [S][5], host
         int sections;
         bool relaxed;
+        bool relaxed_f64;      // PIPE_HIP_PARAM_RELAXED_F64 is set on the stage
     };
     // prepare: the chain WILL launch the fused kernel on this stream (the history goes to its layout)
     virtual bool fuse_view_fir(FirFuseView *, hipStream_t, bool /*prepare*/) { return false; }

@@ -647,7 +647,7 @@ public:
         if (!ols_ || windowed())
             return false;
         if (prepare && (order_after_upload(s) != PIPE_HIP_OK ||
-                        ensure_hist_type(true, s) != PIPE_HIP_OK))  // the fused kernel: float32 history
+                        ensure_hist_type(!v->f64_stream, s) != PIPE_HIP_OK))  // the fused kernel: the history in the stream's own type
             return false;
         v->hist = hist_[cur_hist_].p;
         v->hist_new = hist_next();
@@ -655,6 +655,7 @@ public:
         v->taps = static_cast<const double *>(taps_[cur_taps_].p);
         v->ntaps = N_;
         v->relaxed = !exact_;
+        v->relaxed_f64 = relaxed_f64_;
         // (the fused chain replaces THREE launches and 4x the traffic: it pays from two transforms per CU, where the
         // FIR alone needs eight to beat its direct form -- 64 Lines x 8 ch x 4096, a rank's share of configs[3] at
         // 8 GPUs: 0.048 ms staged)

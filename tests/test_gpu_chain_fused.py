@@ -414,3 +414,65 @@ def test_a_fused_launch_that_gives_up_is_run_again_staged(monkeypatch):
             err = np.abs(d_out.cpu().numpy().reshape(lines, F, C).astype(np.float64) - w.astype(np.float32).astype(np.float64)) / ulp
             assert err.max() <= 1.0, (k, err.max())
         ch.flush()
+
+
+# ---- float64 buffers: what a Go pipe carries (pipe.go:394,437) -------------------------------------------------------
+@pytest.mark.parametrize("lines,C,ntaps,q,g,calls", [
+    (24, 8, 256, LOWPASS, 0.7071067811865476, [4096, 4096]),      # configs[3] in small, two launches: history and slots carry in float64
+    (256, 2, 256, LOWPASS, 0.5, [4096]),                          # whole Lines per workgroup: the block-local look-back
+    (3, 4, 100, DC_BLOCK, 1.25, [20_000, 30_000]),                # the general look-back
+    (5, 6, 64, TWO_SECTIONS, 0.9, [9_999, 20_001]),               # two sections, ragged ends: the tail kernel on float64 input
+    (256, 2, 256, TWO_SECTIONS, None, [4096]),                    # two sections, block-local
+])
+def test_float64_buffers_take_the_fused_kernel_only_when_asked(lines, C, ntaps, q, g, calls, monkeypatch):
+    """Without PIPE_HIP_PARAM_RELAXED_F64 a float64 chain is the staged chain of ordered forms, bit for bit the oracle's;
+    with it (set on the chain: every stage gets it) the same calls take the fused kernel with float64 loads and stores,
+    within the sum of the two stages' float64 bounds (include/pipe_hip.h); PIPE_HIP_PARAM_EXACT wins over the opt-in."""
+    from tests import _tol
+    monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
+    frames = sum(calls)
+    taps = synth.fir_lowpass_taps(ntaps)
+    x = np.stack([synth.samples(synth.line_seed(800 + l), 0, frames * C, np.float64).reshape(frames, C) for l in range(lines)])
+
+    def run(relaxed, exact):
+        kw = dict(dtype=np.float64, lines=lines, max_batch=1)
+        stages = [P.Fir(taps, max(calls), C, **kw), P.Biquad(q, max(calls), C, **kw)]
+        if g is not None:
+            stages.append(P.Gain(g, max(calls), C, **kw))
+        with P.Chain(stages) as p:
+            p.start()
+            if relaxed:
+                p.set_relaxed_f64(True)
+            if exact:
+                p.set_exact(True)
+            d_in = torch.from_numpy(x).cuda()
+            outs, names, pos = [], [], 0
+            for n in calls:
+                xin = d_in[:, pos:pos + n, :].contiguous()
+                y = torch.full_like(xin, float("nan"))
+                p.process_batch(xin, y, n)
+                torch.cuda.synchronize()
+                names.append(p.kernel_name())
+                outs.append(y)
+                pos += n
+            p.flush()
+            return torch.cat(outs, dim=1).cpu().numpy(), names
+
+    check = sorted({0, lines // 2, lines - 1})
+    want = {l: oracle_chain(taps, q, g, x[l]) for l in check}
+    plain, names = run(False, False)
+    assert all("chain_fused" not in n and "fir_ols" not in n for n in names), names
+    for l in check:
+        assert np.array_equal(plain[l], want[l]), l
+    got, names = run(True, False)
+    assert all(n.startswith("chain_fused_kernel<f64,f64,") for n in names), names
+    kap = _tol.kappa(q)
+    gg = 1.0 if g is None else abs(g)
+    for l in check:
+        bound = 256.0 * kap * 2.0 ** -53 * np.abs(want[l]).max() + gg * kap * _tol.fir_f64_bound(taps)
+        err = np.abs(got[l] - want[l]).max()
+        assert err <= bound, (l, err, bound)
+    pinned, names = run(True, True)
+    assert all("chain_fused" not in n for n in names), names
+    for l in check:
+        assert np.array_equal(pinned[l], want[l]), l

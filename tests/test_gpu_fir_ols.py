@@ -480,7 +480,7 @@ def test_float64_chain_staged_with_the_relaxed_forms(monkeypatch):
     sum of the two stages' bounds (the biquad's low-pass gain is <= 1: the FIR's error passes through it unamplified up
     to kappa)."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
-    lines, C, F = 6, 2, 4096 * 6
+    lines, C, F = 6, 3, 4096 * 6   # (three channels: an even count takes the FUSED kernel, tests/test_gpu_chain_fused.py)
     taps = synth.fir_lowpass_taps(256)
     q = synth.biquad_rbj_lowpass()
     g = 0.7071067811865476
