@@ -826,6 +826,35 @@ def run_rank(args, rank, world, local, sync, launch):
             r4["parity_stats"] = ps4
             del c_rel, c_ex
             result["c4_chain"] = r4
+        # the same chain on FLOAT64 buffers (what a Go pipe carries): with PIPE_HIP_PARAM_RELAXED_F64 on the chain it takes
+        # the fused kernel too, 16 algorithmic bytes a sample; three rotating sets of 128 + 128 MiB (streaming)
+        try:
+            sets64 = [(torch.empty(n4, dtype=torch.float64, device=dev), torch.empty(n4, dtype=torch.float64, device=dev)) for _ in range(3)]
+        except RuntimeError:
+            sets64 = []
+        if sets64:
+            for q64, (xi, _) in enumerate(sets64):
+                P.synth_fill(xi, synth.line_seed(900 + q64))
+            kw64 = dict(dtype=np.float64, device=local, lines=L4, max_batch=1)
+            with P.Chain([P.Fir(synth.fir_lowpass_taps(N), F, C4, **kw64), P.Biquad(synth.biquad_rbj_lowpass(), F, C4, **kw64),
+                          P.Gain(0.7071067811865476, F, C4, **kw64)]) as ch64:
+                ch64.start()
+                _, ks, nls, kns = timed(ch64, 20, 10, None, None, 0,
+                                        call=[(lambda a=a_, b=b_: ch64.process_batch(a, b, F, stream=stream)) for a_, b_ in sets64])
+                ch64.set_relaxed_f64(True)
+                ch64.start()
+                _, kf, nlf, knf = timed(ch64, 400, 300, None, None, 0,
+                                        call=[(lambda a=a_, b=b_: ch64.process_batch(a, b, F, stream=stream)) for a_, b_ in sets64])
+                msf, mss_ = kf / max(nlf, 1), ks / max(nls, 1)
+                result["c4_chain"]["float64_buffers"] = {
+                    "workload": "the same launch on float64 buffers, PIPE_HIP_PARAM_RELAXED_F64 set (hip.Options{RelaxedFloat64: true})",
+                    "kernel": knf, "avg_kernel_ms": round(msf, 5), "algorithmic_bytes_per_launch": n4 * 16,
+                    "roofline_frac": round(n4 * 16 / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "msamples_per_s": round(n4 / (msf * 1e-3) / 1e6, 1),
+                    "default_without_the_opt_in": {"kernel": kns + " (first stage of the staged chain, bit for bit the oracle's)",
+                                                   "avg_chain_ms": round(mss_, 5),
+                                                   "msamples_per_s": round(n4 / (mss_ * 1e-3) / 1e6, 1)}}
+            del sets64
         # the same chain with 16 buffers per Line and launch (2 GiB per launch: streaming by its size): the kernel once a
         # launch's edges -- everybody's first window at once, the last epilogue alone -- are amortised; it then sits at
         # the socket's power cap (profiles/r04_chain_k_power.jsonl)

@@ -64,7 +64,7 @@ public:
                 (!f64 || (fv.relaxed_f64 && bv.relaxed_f64)) &&
                 bv.sections <= fused::kMaxFusedSections && fv.ntaps >= 16 && fv.ntaps <= 512) {
                 const int64_t L = 1024 - (fv.ntaps - 1 + 31) / 32 * 32;
-                const int64_t items = ((frames + L - 1) / L) * (cfg.channels / 2) * (int64_t)cfg.lines;
+                const int64_t items = ((frames + L - 1) / L) * ((cfg.channels + 1) / 2) * (int64_t)cfg.lines;
                 if (!fused_)
                     fused_.reset(new fused::Plan());
                 if (items >= fv.min_items && fused_->accepts(bv.coeffs, bv.sections, fv.ntaps, frames, s)) {
@@ -294,14 +294,16 @@ private:
             return false;
         if (stages.size() != 2 && stages.size() != 3)
             return false;
-        if (in_dtype != out_dtype || cfg.channels % 2 != 0)
+        if (in_dtype != out_dtype)
             return false;
         if (stages.size() == 3) {
             double g;
             if (!gain_value(stages[2].get(), &g))
                 return false;
         }
-        const uintptr_t pair = 2 * dtype_size(in_dtype);  // (channel pairs are one access)
+        // (channel pairs are one access; an odd channel count -- the last channel alone in its pair, a mono Line: every
+        // frame its own "pair" -- leaves them aligned to an element only)
+        const uintptr_t pair = (cfg.channels % 2 ? 1 : 2) * dtype_size(in_dtype);
         return reinterpret_cast<uintptr_t>(d_in) % pair == 0 && reinterpret_cast<uintptr_t>(d_out) % pair == 0;
     }
 

@@ -102,7 +102,7 @@ void store_flat(double *dst, const Mat &m)
 // state itself -- and writes the series' state slot in its place.
 struct TailArgs {
     int64_t frames, line_stride;
-    int C, N, H, HP, L, tiles_per_line, nseries;  // nseries = lines * C
+    int C, pairs, N, H, HP, L, tiles_per_line, nseries;  // nseries = lines * C; pairs = ceil(C / 2)
     const double *seg_state;                       // [lines][pairs][2][2S]
     unsigned long long *own;                       // [lines][pairs][2 slots][...]: ols32_kernel.hpp
     unsigned epoch;
@@ -178,7 +178,7 @@ chain_tail_kernel(const T *__restrict__ in_base, const T *__restrict__ hist_base
         y = (y0 + y1) + (y2 + y3);
     }
     double st[N2];
-    const double *sp = a.seg_state + ((int64_t)(line * (a.C / 2) + ch / 2) * 2 + (ch & 1)) * N2;
+    const double *sp = a.seg_state + ((int64_t)(line * a.pairs + ch / 2) * 2 + (ch & 1)) * N2;
 #pragma unroll
     for (int j = 0; j < N2; ++j)
         st[j] = sp[j];
@@ -187,7 +187,7 @@ chain_tail_kernel(const T *__restrict__ in_base, const T *__restrict__ hist_base
     if (l5 == 0) {
         constexpr int NV = 2 * N2;
         unsigned long long *slot =
-            ols::own_write_slot<NV>(a.own + (int64_t)(line * (a.C / 2) + ch / 2) * (2 * 2 * NV), a.epoch);
+            ols::own_write_slot<NV>(a.own + (int64_t)(line * a.pairs + ch / 2) * (2 * 2 * NV), a.epoch);
 #pragma unroll
         for (int j = 0; j < N2; ++j)
             ols::own_store(slot + 2 * ((ch & 1) * N2 + j), a.epoch, st[j]);
@@ -196,42 +196,61 @@ chain_tail_kernel(const T *__restrict__ in_base, const T *__restrict__ hist_base
 
 // The biquad stage's own state array <-> the state slots, when a chain changes between its staged
 // and its fused form (one thread per channel pair).
+// (C channels in `pairs` = ceil(C / 2) pairs per Line: an odd count's last pair holds ONE channel -- the other half of
+// its slots is a channel that does not exist, zero on the way in and dropped on the way out)
 template <int S>
 __global__ void chain_state_import_kernel(const double *__restrict__ state, unsigned long long *own, int nseries2,
-                                          unsigned epoch)
+                                          unsigned epoch, int C, int pairs)
 {
-    constexpr int NV = 4 * S;
+    constexpr int N2 = 2 * S, NV = 4 * S;
     const int sid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (sid >= nseries2)
         return;
+    const int line = sid / pairs, c0 = 2 * (sid - line * pairs);
     unsigned long long *o = own + (int64_t)sid * (2 * 2 * NV);
     for (int slot = 0; slot < 2; ++slot)  // equal tags: the reader takes slot 0, the writer slot 1
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-            ols::own_store(o + slot * (2 * NV) + 2 * j, epoch, state[(int64_t)sid * NV + j]);
+        for (int j = 0; j < NV; ++j) {
+            const int c = c0 + j / N2;
+            ols::own_store(o + slot * (2 * NV) + 2 * j, epoch, c < C ? state[((int64_t)line * C + c) * N2 + j % N2] : 0.0);
+        }
 }
 template <int S>
 __global__ void chain_state_export_kernel(double *__restrict__ state, const unsigned long long *own, int nseries2,
-                                          unsigned epoch)
+                                          unsigned epoch, int C, int pairs)
 {
-    constexpr int NV = 4 * S;
+    constexpr int N2 = 2 * S, NV = 4 * S;
     const int sid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (sid >= nseries2)
         return;
+    const int line = sid / pairs, c0 = 2 * (sid - line * pairs);
     double pay[NV];
     ols::own_read<NV>(own + (int64_t)sid * (2 * 2 * NV), epoch, pay);  // (epoch: one no launch has used)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-        state[(int64_t)sid * NV + j] = pay[j];
+    for (int j = 0; j < NV; ++j) {
+        const int c = c0 + j / N2;
+        if (c < C)
+            state[((int64_t)line * C + c) * N2 + j % N2] = pay[j];
+    }
 }
 
 }  // namespace
+
+// S = 1 .. 4 as a compile-time constant
+#define PH_FOR_SECTIONS(Sv, STMT)                  \
+    switch (Sv) {                                  \
+    case 1: { constexpr int SC = 1; STMT; } break; \
+    case 2: { constexpr int SC = 2; STMT; } break; \
+    case 3: { constexpr int SC = 3; STMT; } break; \
+    default: { constexpr int SC = 4; STMT; } break; \
+    }
 
 struct Plan::Impl {
     DevBuf rec, mats[2], seg_state, own, prof;
     PinnedBuf err;            // host-resident, device-visible: the host reads it after any synchronisation
     int *err_dev = nullptr;   // the kernel's alias of it
     int own_series = 0;       // channel pairs the slots were sized for
+    int own_C = 0, own_pairs = 1;  // ... as channels and pairs per Line
     bool in_slots = false;    // the cascade's state lives in the slots (else in the biquad stage's array)
     double *bq_state = nullptr;
     int cur_mats = 0;
@@ -242,6 +261,20 @@ struct Plan::Impl {
     double gain = 1.0;
     FuseConst<1> c1{};
     FuseConst<2> c2{};
+    FuseConst<3> c3{};
+    FuseConst<4> c4{};
+    template <int SC>
+    FuseConst<SC> &fc()
+    {
+        if constexpr (SC == 1)
+            return c1;
+        else if constexpr (SC == 2)
+            return c2;
+        else if constexpr (SC == 3)
+            return c3;
+        else
+            return c4;
+    }
     int D = 1 << 30;
     unsigned epoch = 0;
     size_t rec_granules = 0;
@@ -347,7 +380,9 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
     I.D = Dmax;  // (the slowest section decides)
     std::memcpy(I.c1.c, coeffs, sizeof(double) * 5);
     std::memcpy(I.c2.c, coeffs, sizeof(double) * 5 * (S < 2 ? 1 : 2));
-    I.c1.D = I.c2.D = Dmax;
+    std::memcpy(I.c3.c, coeffs, sizeof(double) * 5 * (S < 3 ? S : 3));
+    std::memcpy(I.c4.c, coeffs, sizeof(double) * 5 * (S < 4 ? S : 4));
+    I.c1.D = I.c2.D = I.c3.D = I.c4.D = Dmax;
     I.cur_mats ^= 1;
     PH_TRY(I.upload.commit(I.mats[I.cur_mats].p, bytes, s));
     I.coeffs.assign(coeffs, coeffs + 5 * S);
@@ -357,14 +392,14 @@ int Plan::prepare(const double *coeffs, int S, int ntaps, hipStream_t s)
 }
 
 // Can this cascade run fused on a call of `frames` frames?  One section: always (slow filters take the
-// general look-back, a ragged end the tail kernel).  Two sections: forgetful filters and Lines that end
-// on a segment boundary only.
+// general look-back, a ragged end the tail kernel).  Two to four sections: forgetful filters only (every section
+// forgets within a look-back window).
 bool Plan::accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipStream_t s)
 {
     if (S == 1)
         return true;
     (void)frames;
-    if (S != 2 || PH_ENV_AB("PIPE_HIP_CHAIN_GENERAL") || PH_ENV_AB("PIPE_HIP_CHAIN_ONE_SECTION"))
+    if (S < 2 || S > kMaxFusedSections || PH_ENV_AB("PIPE_HIP_CHAIN_GENERAL") || PH_ENV_AB("PIPE_HIP_CHAIN_ONE_SECTION"))
         return false;
     if (prepare(coeffs, S, ntaps, s) != PIPE_HIP_OK)
         return false;
@@ -433,7 +468,9 @@ bool Plan::launchable()
                              form_fits<float, 2, false, true>() && form_fits<float, 2, false, false>() &&
                              form_fits<double, 1, true, false>() && form_fits<double, 1, false, true>() &&
                              form_fits<double, 1, false, false>() && form_fits<double, 2, false, true>() &&
-                             form_fits<double, 2, false, false>()
+                             form_fits<double, 2, false, false>() && form_fits<float, 3, false, false>() &&
+                             form_fits<float, 4, false, false>() && form_fits<double, 3, false, false>() &&
+                             form_fits<double, 4, false, false>()
                          ? 1
                          : 2;
     return known[dev] == 1;
@@ -446,12 +483,9 @@ int Plan::export_state(hipStream_t s)
     Impl &I = *impl_;
     if (!I.in_slots)
         return PIPE_HIP_OK;
-    if (I.S == 2)
-        hipLaunchKernelGGL(chain_state_export_kernel<2>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
-                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
-    else
-        hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
-                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1);
+    PH_FOR_SECTIONS(I.S, hipLaunchKernelGGL(chain_state_export_kernel<SC>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                                            I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch + 1,
+                                            I.own_C, I.own_pairs))
     PH_HIP(hipGetLastError());
     I.in_slots = false;
     return PIPE_HIP_OK;
@@ -466,12 +500,9 @@ int Plan::rollback(hipStream_t s)
         return PIPE_HIP_OK;
     // own_read takes the newer slot that is NOT tagged with the epoch it is given: given the failed launch's own
     // epoch it skips whatever that launch wrote
-    if (I.S == 2)
-        hipLaunchKernelGGL(chain_state_export_kernel<2>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
-                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch);
-    else
-        hipLaunchKernelGGL(chain_state_export_kernel<1>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
-                           I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch);
+    PH_FOR_SECTIONS(I.S, hipLaunchKernelGGL(chain_state_export_kernel<SC>, dim3((unsigned)((I.own_series + 255) / 256)), dim3(256), 0, s,
+                                            I.bq_state, static_cast<const unsigned long long *>(I.own.p), I.own_series, I.epoch, I.own_C,
+                                            I.own_pairs))
     PH_HIP(hipGetLastError());
     I.in_slots = false;
     ++I.epoch;  // (the failed launch's tags stay behind in the records and slots: never reused)
@@ -616,7 +647,8 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     a.H = fir.ntaps - 1;
     a.HP = (a.H + 31) / 32 * 32;  // a tile's first output opens a segment (ols32_kernel.hpp)
     a.L = ols::kM32 - a.HP;
-    a.pairs = channels / 2;
+    a.pairs = (channels + 1) / 2;  // (an odd count: the last channel alone in its pair, as in the FIR alone)
+    a.odd = channels & 1;
     a.lines = lines;
     a.tiles_per_line = (int)((frames + a.L - 1) / a.L);
     a.ipl = a.tiles_per_line * a.pairs;
@@ -639,23 +671,20 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     }
     // the cascade's state: in the tagged slots while the chain stays fused (ols32_kernel.hpp)
     const int nseries2 = lines * a.pairs;
-    if (I.own_series != nseries2) {
+    if (I.own_series != nseries2 || I.own_C != channels) {
         PH_TRY(export_state(s));
         PH_HIP(hipStreamSynchronize(s));
         PH_TRY(I.own.alloc(sizeof(unsigned long long) * (size_t)nseries2 * (2 * 2 * NV)));
         I.own_series = nseries2;
+        I.own_C = channels;
+        I.own_pairs = a.pairs;
     }
     I.bq_state = bq.state;
     if (!I.in_slots) {
         ++I.epoch;
-        if (S == 2)
-            hipLaunchKernelGGL(chain_state_import_kernel<2>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
-                               static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
-                               I.epoch);
-        else
-            hipLaunchKernelGGL(chain_state_import_kernel<1>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
-                               static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p), nseries2,
-                               I.epoch);
+        PH_FOR_SECTIONS(S, hipLaunchKernelGGL(chain_state_import_kernel<SC>, dim3((unsigned)((nseries2 + 255) / 256)), dim3(256), 0, s,
+                                              static_cast<const double *>(bq.state), static_cast<unsigned long long *>(I.own.p),
+                                              nseries2, I.epoch, channels, a.pairs))
         PH_HIP(hipGetLastError());
         I.in_slots = true;
     }
@@ -694,14 +723,15 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
     // records and windows; PIPE_HIP_CHAIN_GENERAL=1 forces the general one (tests)
     static const bool force_general = PH_ENV_AB("PIPE_HIP_CHAIN_GENERAL") != nullptr;
     const bool general = force_general || I.D > 32;
-    if (S < 1 || S > kMaxFusedSections || (S == 2 && general))
+    if (S < 1 || S > kMaxFusedSections || (S >= 2 && general))
         return PIPE_HIP_EINVAL;  // (Plan::accepts said otherwise: the caller did not ask)
-    I.c1.gain = I.c2.gain = has_gain ? gain : 1.0;
+    I.c1.gain = I.c2.gain = I.c3.gain = I.c4.gain = has_gain ? gain : 1.0;
     // Block-local look-back (ols32_kernel.hpp): at least as many Lines as CUs -- a workgroup per CU,
     // whole Lines per workgroup, balanced to within one Line -- and predecessors within the record
     // ring's reach.  PIPE_HIP_CHAIN_LOCAL=0 switches it off (tests, A/B).
     const char *local_env = PH_ENV_AB("PIPE_HIP_CHAIN_LOCAL");
-    const bool local = !general && !(local_env && local_env[0] == '0') && lines >= P.cus &&
+    // (three and four sections: a ring of records per section does not fit the LDS next to the tap spectrum -- the global look-back)
+    const bool local = !general && S <= 2 && !(local_env && local_env[0] == '0') && lines >= P.cus &&
                        (int64_t)I.D * a.pairs <= (S == 2 ? ols::kLocalReach2 : ols::kLocalReach) &&
                        (lines % P.cus == 0 || lines >= 8 * P.cus);
     a.local = local ? 1 : 0;
@@ -709,6 +739,15 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         const char *e = PH_ENV_AB("PIPE_HIP_CHAIN_STAGGER");  // A/B knob
         a.stagger = e ? std::atoi(e) : 0;
     }
+    if (S == 3) {
+        I.c3.D = I.D;
+        *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad3+gain>" : "chain_fused_kernel<f32,f32,fir+biquad3+gain>";
+        PH_TRY((launch<3, false, false>(f64, P, d_in, d_out, fir.hist, a, fa, I.c3, s, timer)));
+    } else if (S == 4) {
+        I.c4.D = I.D;
+        *kernel_name = f64 ? "chain_fused_kernel<f64,f64,fir+biquad4+gain>" : "chain_fused_kernel<f32,f32,fir+biquad4+gain>";
+        PH_TRY((launch<4, false, false>(f64, P, d_in, d_out, fir.hist, a, fa, I.c4, s, timer)));
+    } else
     if (S == 2) {
         // two sections: the sections one after the other over the tile in segment layout (ols32_kernel.hpp)
         I.c2.D = I.D;
@@ -740,6 +779,7 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.frames = frames;
         ta.line_stride = a.line_stride;
         ta.C = channels;
+        ta.pairs = a.pairs;
         ta.N = a.N;
         ta.H = a.H;
         ta.HP = a.HP;
@@ -751,18 +791,15 @@ int Plan::run(const pipe_hip_processor::FirFuseView &fir, const pipe_hip_process
         ta.epoch = I.epoch;
         const unsigned tgrid = (unsigned)((ta.nseries + kTailSeries - 1) / kTailSeries);
         const size_t tlds = sizeof(double) * (size_t)(32 + a.H) * kTailSeries;
-        if (S == 2 && f64)
-            hipLaunchKernelGGL((chain_tail_kernel<2, double>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const double *>(d_in), static_cast<const double *>(fir.hist), fir.taps, ta, I.c2);
-        else if (S == 2)
-            hipLaunchKernelGGL((chain_tail_kernel<2, float>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c2);
-        else if (f64)
-            hipLaunchKernelGGL((chain_tail_kernel<1, double>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const double *>(d_in), static_cast<const double *>(fir.hist), fir.taps, ta, I.c1);
-        else
-            hipLaunchKernelGGL((chain_tail_kernel<1, float>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
-                               static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta, I.c1);
+        if (f64) {
+            PH_FOR_SECTIONS(S, hipLaunchKernelGGL((chain_tail_kernel<SC, double>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                                                  static_cast<const double *>(d_in), static_cast<const double *>(fir.hist), fir.taps, ta,
+                                                  I.fc<SC>()))
+        } else {
+            PH_FOR_SECTIONS(S, hipLaunchKernelGGL((chain_tail_kernel<SC, float>), dim3(tgrid), dim3(32 * kTailSeries), tlds, s,
+                                                  static_cast<const float *>(d_in), static_cast<const float *>(fir.hist), fir.taps, ta,
+                                                  I.fc<SC>()))
+        }
         PH_HIP(hipGetLastError());
     }
     return PIPE_HIP_OK;

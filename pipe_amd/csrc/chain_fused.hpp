@@ -8,13 +8,13 @@
 namespace pipehip {
 namespace fused {
 
-// One or two sections.  A cascade run as ONE 2S x 2S recurrence does not fit a wave's registers (the
+// One to four sections.  A cascade run as ONE 2S x 2S recurrence does not fit a wave's registers (the
 // 4 x 4 matrices of two sections: 200+ spilled, and hipcc places spill stores inside exec-masked
 // regions of this kernel -- lanes that were masked off then reload garbage); two sections run as two
 // passes of the one-section machinery over the tile in segment layout (ols32_kernel.hpp,
 // fused_epilogue_sections), spill-free.  Only spill-free instantiations are launched
 // (scripts/check_spills.sh); longer cascades take the staged chain.
-constexpr int kMaxFusedSections = 2;
+constexpr int kMaxFusedSections = 4;  // (three and four: the global look-back only, round 6)
 
 class Plan {
 public:
@@ -33,7 +33,7 @@ public:
             KernelTimer *timer, const char **kernel_name);
     // the fused kernel's workgroup (512 threads + its LDS) fits a CU of the current device
     static bool launchable();
-    // this cascade on a call of `frames` frames: one section always; two sections when every section
+    // this cascade on a call of `frames` frames: one section always; two to four sections when every section
     // forgets within a look-back window
     bool accepts(const double *coeffs, int S, int ntaps, int64_t frames, hipStream_t s);
     // EHIP if a launch since the last poll gave up waiting for a predecessor tile.  The caller has

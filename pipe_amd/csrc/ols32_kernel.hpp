@@ -77,7 +77,8 @@ struct Args32 {
     int d_slot, d_line;   // the wave stride of the launch as (slot, Line) digits
     int64_t mono_shift;   // MONO kernels (one channel): the frames between the two tiles a half-wave's complex sequence carries
     int odd;              // C is odd: the last "pair" is ONE channel (its imaginary part: whatever follows it in memory,
-                          // finite and unused -- real taps keep the parts apart; only its real part is stored).  S = 0 only
+                          // finite and unused -- real taps keep the parts apart; only its real part is stored; the
+                          // fused chain's epilogue runs the phantom channel like any other and drops it)
     void *hist_new;       // float64 elements (S = 0), the stream's float32 (fused chain, S > 0)
 };
 
@@ -1357,7 +1358,7 @@ fir_ols32_kernel(const TIn *__restrict__ in_base, TOut *__restrict__ out_base,
                 base, 0, bytes31((a.frames - t00) * a.C * (int64_t)sizeof(TOut)), 0x00020000);
             const int o0 = (((tile - tile0) * a.L + l5 - a.HP) * a.C + c0) * (int)sizeof(TOut);
             const int i0 = valid ? l5 - a.HP : -2048;  // window index - HP of register 0: outputs need >= 0
-            const bool lone = S == 0 && a.odd && c0 + 1 == a.C;  // (uniform over a half-wave)
+            const bool lone = a.odd && c0 + 1 == a.C;  // (uniform over a half-wave)
             if constexpr (MONO) {
                 const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
                     base + a.mono_shift, 0, bytes31c((a.frames - t00 - a.mono_shift) * (int64_t)sizeof(TOut)), 0x00020000);

@@ -36,6 +36,8 @@ def ulps(got, want64):
 DC_BLOCK = np.array([[1.0, -1.0, 0.0, -0.9995, 0.0]])             # pole at 0.9995: forgets over ~10^4 frames
 LOWPASS = synth.biquad_rbj_lowpass()                              # forgets within one 769-frame tile
 TWO_SECTIONS = np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0)])
+THREE_SECTIONS = np.vstack([TWO_SECTIONS, synth.biquad_rbj_lowpass(1500.0, q=1.1)])
+FOUR_SECTIONS = np.vstack([THREE_SECTIONS, synth.biquad_rbj_lowpass(5000.0, q=0.6)])
 
 
 def run_chain(taps, q, g, x, calls, exact=False):
@@ -80,6 +82,15 @@ def oracle_chain(taps, q, g, x):
     (9, 4, 3 * 4096, 256, TWO_SECTIONS, 0.7, [4096, 4096, 4096]),      # two sections, three launches: both sections' slots carry
     (3, 2, 20_032, 100, TWO_SECTIONS, 1.5, [10_016, 4000, 6016]),      # ... a ragged end in the middle (tail kernel, two sections)
     (7, 16, 5_000, 16, LOWPASS, 2.0, [5_000]),                         # shortest filter, first output in lane 0
+    (9, 4, 3 * 4096, 256, THREE_SECTIONS, 0.7, [4096, 4096, 4096]),    # three sections (round 6: the global look-back), three launches
+    (3, 2, 20_032, 100, FOUR_SECTIONS, 1.5, [10_016, 4000, 6016]),     # four sections, a ragged end in the middle (tail kernel, four sections)
+    (40, 8, 4096, 256, FOUR_SECTIONS, None, [4096]),                   # four sections at the configs[3] shape in small
+    # odd channel counts (round 6): the last channel alone in its pair, its other half a channel that does not exist
+    (5, 3, 20_000, 100, LOWPASS, 0.9, [9_999, 10_001]),                # three channels, ragged calls (tail kernel: three series a Line)
+    (8, 1, 30_000, 256, LOWPASS, None, [12_000, 18_000]),              # mono Lines: every frame its own "pair"
+    (3, 5, 3 * 4096, 64, TWO_SECTIONS, 1.1, [4096, 4096, 4096]),       # five channels, two sections, three launches
+    (256, 3, 4096, 256, LOWPASS, 0.5, [4096]),                         # three channels, whole Lines per workgroup (block-local)
+    (2, 7, 9_000, 200, DC_BLOCK, 1.0, [4_000, 5_000]),                 # seven channels, the general look-back
 ])
 def test_fused_chain_within_one_ulp_of_oracle(lines, C, frames, ntaps, q, g, calls, monkeypatch):
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
@@ -423,6 +434,8 @@ def test_a_fused_launch_that_gives_up_is_run_again_staged(monkeypatch):
     (3, 4, 100, DC_BLOCK, 1.25, [20_000, 30_000]),                # the general look-back
     (5, 6, 64, TWO_SECTIONS, 0.9, [9_999, 20_001]),               # two sections, ragged ends: the tail kernel on float64 input
     (256, 2, 256, TWO_SECTIONS, None, [4096]),                    # two sections, block-local
+    (6, 3, 128, LOWPASS, 0.8, [10_000, 6_011]),                   # three channels, ragged
+    (9, 4, 256, FOUR_SECTIONS, 1.0, [4096, 4096]),                # four sections
 ])
 def test_float64_buffers_take_the_fused_kernel_only_when_asked(lines, C, ntaps, q, g, calls, monkeypatch):
     """Without PIPE_HIP_PARAM_RELAXED_F64 a float64 chain is the staged chain of ordered forms, bit for bit the oracle's;

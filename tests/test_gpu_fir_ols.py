@@ -480,8 +480,8 @@ def test_float64_chain_staged_with_the_relaxed_forms(monkeypatch):
     sum of the two stages' bounds (the biquad's low-pass gain is <= 1: the FIR's error passes through it unamplified up
     to kappa)."""
     monkeypatch.setenv("PIPE_HIP_FIR_OLS_MIN_ITEMS", "1")
-    lines, C, F = 6, 3, 4096 * 6   # (three channels: an even count takes the FUSED kernel, tests/test_gpu_chain_fused.py)
-    taps = synth.fir_lowpass_taps(256)
+    lines, C, F = 6, 2, 4096 * 6
+    taps = synth.fir_lowpass_taps(600)   # (more than 512 taps: up to 512 the chain takes the FUSED kernel, tests/test_gpu_chain_fused.py)
     q = synth.biquad_rbj_lowpass()
     g = 0.7071067811865476
     x = np.stack([synth.samples(synth.line_seed(720 + l), 0, F * C, np.float64).reshape(F, C) for l in range(lines)])

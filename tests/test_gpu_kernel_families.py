@@ -20,6 +20,7 @@ F = 4096
 Q1 = synth.biquad_rbj_lowpass()
 Q2 = np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0)])
 Q3 = np.vstack([synth.biquad_rbj_lowpass(fc=f) for f in (500.0, 1500.0, 4000.0)])
+Q4 = np.vstack([Q2, synth.biquad_rbj_lowpass(1500.0, q=1.1), synth.biquad_rbj_lowpass(5000.0, q=0.6)])
 DC_BLOCK = np.array([[1.0, -1.0, 0.0, -0.9995, 0.0]])  # forgets over ~10^4 frames: the fused chain's general look-back
 TAPS = synth.fir_lowpass_taps(256, f32_rounded=True)
 TAPS_LONG = synth.fir_lowpass_taps(1100, fc=0.07, f32_rounded=True)
@@ -286,6 +287,8 @@ FORMS = {
     "chain_fused_kernel<fir+biquad1+gain,general>": _chain(96, 8, F, DC_BLOCK, None, 52, (0, 95)),
     "chain_fused_kernel<fir+biquad2+gain>": _chain(96, 8, F, Q2, 0.9, 53, (0, 95)),
     "chain_fused_kernel<fir+biquad2+gain,local>": _chain(256, 2, F, Q2, 1.25, 54, (0, 255)),
+    "chain_fused_kernel<fir+biquad3+gain>": _chain(96, 8, F, Q4[:3], 0.9, 55, (0, 95)),
+    "chain_fused_kernel<fir+biquad4+gain>": _chain(96, 8, F, Q4, None, 56, (0, 95)),
     "biquad_kernel<>": _biquad_register,
     "biquad_lds_kernel<>": _biquad_lds,
     "biquad_lds_sp_kernel<>": _biquad_lds_sp,
