@@ -4,7 +4,7 @@
 #   - rebuilds nothing (the in-tree libraries are what travels; `make -q` says whether they are current),
 #   - runs scripts/gpu_final_gate.sh on a fresh MI355X, copies its report to profiles/<tag>_gate.txt and commits it.
 # No code commit may follow it (only this report).
-TAG=${1:-r05}
+TAG=${1:-r06}
 if [ -n "$(git status --porcelain)" ]; then echo "tree is dirty: commit first"; git status --short | head; exit 1; fi
 ( cd pipe_amd/csrc && make -q ) || { echo "libpipe_hip.so is older than its sources: make first"; exit 1; }
 SHA=$(git rev-parse HEAD)

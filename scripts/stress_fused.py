@@ -21,7 +21,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 filters = [synth.biquad_rbj_lowpass(), synth.biquad_rbj_lowpass(3000.0), np.array([[1.0, -1.0, 0.0, -0.9995, 0.0]]),
            # two sections (one ring of records per section)
            np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0)]),
-           np.vstack([synth.biquad_rbj_lowpass(5000.0, q=0.5), synth.biquad_rbj_lowpass(1500.0)])]
+           np.vstack([synth.biquad_rbj_lowpass(5000.0, q=0.5), synth.biquad_rbj_lowpass(1500.0)]),
+           # three and four sections (round 6: the global look-back)
+           np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0), synth.biquad_rbj_lowpass(1500.0, q=1.1)]),
+           np.vstack([synth.biquad_rbj_lowpass(3000.0), synth.biquad_rbj_lowpass(700.0, q=2.0), synth.biquad_rbj_lowpass(1500.0, q=1.1),
+                      synth.biquad_rbj_lowpass(5000.0, q=0.6)])]
 
 
 def run(taps, q, g, x, calls, local):
@@ -47,8 +51,8 @@ def run(taps, q, g, x, calls, local):
 
 t0 = time.time()
 for it in range(iters):
-    lines = int(rng.choice([256, 256, 512, 768, 2100]))
-    C = int(rng.choice([2, 4, 6, 8]))
+    lines = int(rng.choice([40, 256, 256, 512, 768, 2100]))
+    C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))   # (odd counts, round 6: the last channel alone in its pair)
     ntaps = int(rng.choice([16, 64, 256, 300]))
     q = filters[int(rng.integers(len(filters)))]
     ncalls = int(rng.integers(1, 4))
