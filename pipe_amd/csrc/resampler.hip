@@ -748,7 +748,13 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
     constexpr int W = TT + DMIN + 1;  // frames a pair reads
     constexpr int G4 = 4, NG = (W + G4 - 1) / G4, NPOS = NG * G4;
     const int nwaves = (int)gridDim.x;
-    const int slot = (int)blockIdx.x % t.G;
+    // Waves that stand side by side in the stream on ONE XCD (workgroup b runs on XCD b % 8): wave xb of the launch's
+    // order is the (b / 8)-th workgroup of XCD b % 8, so that XCD x holds the waves [x n / 8, (x + 1) n / 8) -- the G slots of
+    // a group and the groups next to it, whose windows overlap by the filter's length, share their overlap through that
+    // XCD's L2 (round 5 dealt them round-robin over the XCDs: every overlap was fetched twice, 1.21 x the algorithmic bytes)
+    const int nb8 = (int)gridDim.x;
+    const int xb = nb8 % 8 == 0 ? ((int)blockIdx.x % 8) * (nb8 / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int slot = xb % t.G;
     const int ngroups = t.groups_per_line * a.lines, gstride = nwaves / t.G;
 #ifdef PH_RS_PROF
     unsigned long long rsprof[5] = {}, rslast = __builtin_amdgcn_s_memtime();
@@ -858,7 +864,7 @@ __global__ void __launch_bounds__(64) resample_wave_kernel(const WaveArgs t)
         __builtin_amdgcn_wave_barrier();
     };
 
-    int gid = (int)blockIdx.x / t.G;
+    int gid = xb / t.G;
     if (gid >= ngroups)
         return;
     PH_RW_STEP(cs_, gid);
@@ -1527,7 +1533,16 @@ private:
         // twelve waves a CU (three a SIMD: the kernel's registers), whole groups of them
         int64_t waves = ngroups * G;
         const char *wpc = PH_ENV_AB("PIPE_HIP_RESAMPLE_WAVES_PER_CU");  // A/B: resident waves per CU
-        const int64_t cap = (int64_t)(wpc ? std::atoi(wpc) : 12) * cus_ / G * G;
+        int64_t cap = (int64_t)(wpc ? std::atoi(wpc) : 12) * cus_ / G * G;
+        {
+            // ... and of eight where that costs less than a tenth of them (the XCD-major order of the kernel needs it)
+            int64_t l = G;
+            while (l % 8 != 0)
+                l += G;
+            const int64_t cap8 = cap / l * l;
+            if (cap8 * 10 >= cap * 9)
+                cap = cap8;
+        }
         if (waves > cap && cap >= G)
             waves = cap;
         const size_t lds = sizeof(double) * 4 * (size_t)t.plane;
