@@ -154,6 +154,25 @@ typedef enum pipe_hip_param {
                                   carry it takes the FUSED kernel on float64 buffers as it does on float32 ones
                                   (one read and one write of the buffers, 16 bytes a sample); bound as tested
                                   (tests/test_gpu_chain_fused.py): the sum of the two stages' bounds above. */
+    PIPE_HIP_PARAM_RESIDENT_SHARED = 7, /* 1 value: != 0 as PIPE_HIP_PARAM_RESIDENT, for SEVERAL handles of one device (up to 16):
+                                  they share the device's ONE doorbell queue, each queueing its next buffer's work at
+                                  the queue's tail while its current buffer runs.  A hardware queue runs in order, so
+                                  this pays exactly when the handles are called in the order they were called last
+                                  time and never concurrently -- what pipe.Run's synchronous executor does: all Lines
+                                  of a context in one goroutine, round-robin, a Line's stages in order (run.go:37-52,
+                                  112-132).  Then every stage of every Line has the doorbell's latency (measured: 10.8
+                                  us a call for 1 to 16 handles where the plain path takes 11.7; profiles/
+                                  r06_shared_doorbell_queue.txt).  A call that finds other handles' work AHEAD of its
+                                  own in the queue rings those doorbells first: that work runs on stale input and is
+                                  taken back by its owners at their next call (one wasted launch and one plain-path
+                                  call each; counted as dropped_by_entry) -- correct in any order, but in the
+                                  asynchronous mode (a goroutine per component, merger.go:25-30: arrival order is
+                                  anybody's) it costs 27 us a call, so ask for it in the synchronous mode only.
+                                  Calls of the sharing handles serialise on one lock (they are not concurrent in that
+                                  mode anyway).  Any other entry on a sharing handle (start, flush, a mutation, a batch
+                                  call) first takes back EVERYTHING queued on the device.  Exclusive holder and sharers
+                                  exclude each other: PIPE_HIP_EBUSY.  Value 0 leaves the queue.  Results: bit for bit
+                                  the plain path's, as with PIPE_HIP_PARAM_RESIDENT. */
     PIPE_HIP_PARAM_DEBUG = 5     /* 2 values {tile, limit_us}: the next launch of a look-back form (fused chain, tile
                                   biquad) fails on demand -- its tiles of that index publish nothing and a wait gives
                                   up after limit_us -- the failure a preempted predecessor tile causes.  A

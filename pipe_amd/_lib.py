@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PIPE_HIP_LIB") or os.path.join(_HERE, "lib", "libpipe
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ECAP, ESTATE, EBUSY = range(8)
 F32, F64 = 0, 1
-PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS, PARAM_EXACT, PARAM_RESIDENT, PARAM_DEBUG, PARAM_RELAXED_F64 = 0, 1, 2, 3, 4, 5, 6
+PARAM_GAIN, PARAM_TAPS, PARAM_COEFFS, PARAM_EXACT, PARAM_RESIDENT, PARAM_DEBUG, PARAM_RELAXED_F64, PARAM_RESIDENT_SHARED = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class Config(C.Structure):

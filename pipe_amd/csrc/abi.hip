@@ -5,6 +5,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -419,10 +420,19 @@ struct pipe_hip_processor::Overlap {
 // stale and leave; the owner waits for its own stale work and takes it back at its next entry.
 namespace {
 constexpr int kMaxDevices = 64;
+constexpr size_t kMaxSharers = 16;
 struct Door {
-    pipe_hip_processor *owner = nullptr;  // the handle that holds this device's doorbell
+    pipe_hip_processor *owner = nullptr;  // the handle that holds this device's doorbell (exclusive: PIPE_HIP_PARAM_RESIDENT)
     hipStream_t stream = nullptr;         // hardware queue of its own; made once, never destroyed
+    // PIPE_HIP_PARAM_RESIDENT_SHARED: handles that share the doorbell queue, and whose work is parked in it, oldest first.
+    // `qmu` is held for the whole of a sharing handle's call (the calls are not concurrent in the mode this is for);
+    // foreign threads -- the watchdog, a handle about to free memory -- only TRY it.  Lock order: g_door_mu, then qmu.
+    std::vector<pipe_hip_processor *> sharers;
+    std::deque<pipe_hip_processor *> order;
+    std::mutex *qmu = new std::mutex;
+    std::chrono::steady_clock::time_point last_call{};
 };
+thread_local int t_holds_qmu = -1;  // device whose qmu the calling thread holds
 // (never destroyed: the watchdog thread and the exit hook may still look at them while statics are torn down)
 std::mutex &g_door_mu = *new std::mutex;  // guards g_door[].owner; lock order: g_door_mu, then TRY a handle's resident.mu
 Door *g_door = new Door[kMaxDevices];
@@ -465,6 +475,40 @@ int resident_wait(pipe_hip_processor *p, unsigned k)
     return __atomic_load_n(p->resident.done(), __ATOMIC_ACQUIRE) == k ? PIPE_HIP_OK : PIPE_HIP_EHIP;
 }
 constexpr int kResidentUnsupported = -1000;  // resident_arm: the stream wait could not be queued (not an ABI status)
+// ---- the shared doorbell queue (PIPE_HIP_PARAM_RESIDENT_SHARED); the device's qmu is held by the caller ----
+// every parked entry is rung, its owner's work marked stale (it runs on whatever its staging buffer holds and is
+// taken back by its owner): nothing is waited for
+void shared_ring_all(Door &D, bool by_watchdog)
+{
+    using RS = pipe_hip_processor::Resident;
+    while (!D.order.empty()) {
+        pipe_hip_processor *q = D.order.front();
+        D.order.pop_front();
+        if (q->resident.state.load(std::memory_order_acquire) == RS::kArmed) {
+            __atomic_store_n(q->resident.bell(), q->resident.seq, __ATOMIC_RELEASE);
+            q->resident.state.store(RS::kStale, std::memory_order_release);
+            (by_watchdog ? q->resident.dropped_by_watchdog : q->resident.dropped_by_entry).fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+}
+// the entries AHEAD of p's are rung and marked stale (the prediction of the call order failed), then p's own is rung:
+// true when p had an entry in the queue
+bool shared_ring_through(Door &D, pipe_hip_processor *p)
+{
+    using RS = pipe_hip_processor::Resident;
+    while (!D.order.empty()) {
+        pipe_hip_processor *q = D.order.front();
+        D.order.pop_front();
+        __atomic_store_n(q->resident.bell(), q->resident.seq, __ATOMIC_RELEASE);
+        if (q == p)
+            return true;
+        if (q->resident.state.load(std::memory_order_acquire) == RS::kArmed) {
+            q->resident.state.store(RS::kStale, std::memory_order_release);
+            q->resident.dropped_by_entry.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    return false;
+}
 // queue the work of a buffer of `frames` frames behind the next doorbell value (resident.mu held, state idle)
 int resident_arm(pipe_hip_processor *p, int32_t frames)
 {
@@ -494,6 +538,8 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
         // stream the slow way and take back whatever part of the launch was queued
         if (we != hipSuccess)
             (void)hipGetLastError();
+        if (R.shared)
+            shared_ring_all(g_door[p->cfg.device], false);  // (other handles' work ahead of ours in the queue: the stream could not drain)
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
         (void)hipStreamSynchronize(p->stream);
         __atomic_store_n(R.done(), k, __ATOMIC_RELEASE);  // (what the missing store would have written)
@@ -521,10 +567,46 @@ int resident_cancel_locked(pipe_hip_processor *p)
     p->rollback_launch();
     return PIPE_HIP_OK;
 }
+// Shared queue: EVERYTHING parked on the device is taken back (qmu held) -- rung, waited for, pointed back -- so that
+// whatever the calling entry does next on the doorbell stream finds the queue empty; what the queued runs replaced is freed.
+int shared_cancel_all_locked(Door &D)
+{
+    using RS = pipe_hip_processor::Resident;
+    shared_ring_all(D, false);
+    int rc = PIPE_HIP_OK;
+    for (pipe_hip_processor *q : D.sharers) {
+        pipe_hip_processor::Resident &R = q->resident;
+        if (R.state.load(std::memory_order_acquire) == RS::kStale) {
+            const int rq = resident_wait(q, R.seq);
+            R.state.store(RS::kIdle, std::memory_order_release);
+            if (rq == PIPE_HIP_OK)
+                q->rollback_launch();
+            else
+                rc = rq;
+        }
+    }
+    for (pipe_hip_processor *q : D.sharers) {
+        for (const DeferredFree &f : q->resident.frees)
+            (void)(f.pinned ? hipHostFree(f.p) : hipFree(f.p));
+        q->resident.frees.clear();
+    }
+    return rc;
+}
+struct QmuHold {  // the device's queue lock, and the note that this thread holds it
+    std::unique_lock<std::mutex> lk;
+    int prev;
+    explicit QmuHold(Door &D, int device) : lk(*D.qmu), prev(t_holds_qmu) { t_holds_qmu = device; }
+    ~QmuHold() { t_holds_qmu = prev; }
+};
 int resident_cancel(pipe_hip_processor *p)
 {
     if (!p->resident.mail.p)
         return PIPE_HIP_OK;
+    if (p->resident.shared) {
+        Door &D = g_door[p->cfg.device];
+        QmuHold hold(D, p->cfg.device);
+        return shared_cancel_all_locked(D);
+    }
     std::lock_guard<std::mutex> lk(p->resident.mu);
     PH_TRY(resident_cancel_locked(p));
     // (nothing of this handle is parked now, and it is the only handle of its device that ever parks anything: what
@@ -561,6 +643,12 @@ void resident_ring_device(int device, const pipe_hip_processor *self)
     pipe_hip_processor *o = g_door[device].owner;
     if (o && o != self)
         resident_ring_foreign(o, false, false);
+    Door &D = g_door[device];
+    if (!D.sharers.empty() && t_holds_qmu != device) {  // (a sharing handle's own entry has emptied the queue already)
+        std::unique_lock<std::mutex> ql(*D.qmu, std::try_to_lock);
+        if (ql.owns_lock())
+            shared_ring_all(D, false);
+    }
 }
 void resident_ring_all()  // process exit: no queue may be left waiting for a host that has gone
 {
@@ -569,17 +657,34 @@ void resident_ring_all()  // process exit: no queue may be left waiting for a ho
         if (pipe_hip_processor *o = g_door[d].owner)
             if (o->resident.mail.p && o->resident.state.load() == pipe_hip_processor::Resident::kArmed)
                 __atomic_store_n(o->resident.bell(), o->resident.seq, __ATOMIC_RELEASE);
+    for (int d = 0; d < kMaxDevices; ++d)
+        for (pipe_hip_processor *q : g_door[d].sharers)
+            if (q->resident.mail.p)
+                __atomic_store_n(q->resident.bell(), q->resident.seq, __ATOMIC_RELEASE);
 }
 void resident_watchdog()
 {
     for (;;) {
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
         std::lock_guard<std::mutex> lk(g_door_mu);
-        for (int d = 0; d < kMaxDevices; ++d)
+        for (int d = 0; d < kMaxDevices; ++d) {
             if (pipe_hip_processor *o = g_door[d].owner)
                 resident_ring_foreign(o, true, true);
+            Door &D = g_door[d];
+            if (!D.sharers.empty()) {  // (sharers change under g_door_mu; the queue itself is looked at under its lock)
+                std::unique_lock<std::mutex> ql(*D.qmu, std::try_to_lock);
+                if (ql.owns_lock() && !D.order.empty()) {
+                    int idle_ms = 250;
+                    for (pipe_hip_processor *q : D.sharers)
+                        idle_ms = q->resident.idle_ms < idle_ms ? q->resident.idle_ms : idle_ms;
+                    if (std::chrono::steady_clock::now() - D.last_call >= std::chrono::milliseconds(idle_ms))
+                        shared_ring_all(D, true);
+                }
+            }
+        }
     }
 }
+int door_prepare(int d);
 // the device's doorbell for `p` (its device selected): PIPE_HIP_EBUSY when another handle holds it
 int resident_acquire(pipe_hip_processor *p)
 {
@@ -589,8 +694,15 @@ int resident_acquire(pipe_hip_processor *p)
     std::lock_guard<std::mutex> lk(g_door_mu);
     if (g_door[d].owner == p)
         return PIPE_HIP_OK;
-    if (g_door[d].owner)
+    if (g_door[d].owner || !g_door[d].sharers.empty())
         return PIPE_HIP_EBUSY;
+    PH_TRY(door_prepare(d));
+    g_door[d].owner = p;
+    return PIPE_HIP_OK;
+}
+// the device's doorbell stream, the exit hook and the watchdog (g_door_mu held)
+int door_prepare(int d)
+{
     static bool hooked = false;
     if (!hooked) {
         hooked = true;
@@ -613,7 +725,6 @@ int resident_acquire(pipe_hip_processor *p)
         }
         g_door[d].stream = s;
     }
-    g_door[d].owner = p;
     return PIPE_HIP_OK;
 }
 void resident_release(pipe_hip_processor *p)
@@ -628,10 +739,13 @@ void resident_release(pipe_hip_processor *p)
 hipStream_t resident_stream(int device) { return g_door[device].stream; }
 
 // switch the doorbell path of `p` on / off (its entry has run: nothing of its own is queued)
+int resident_enable_shared(pipe_hip_processor *p, double value);
 int resident_enable(pipe_hip_processor *p, double value)
 {
     pipe_hip_processor::Resident &R = p->resident;
     if (value == 0.0) {
+        if (R.enabled && R.shared)
+            return resident_enable_shared(p, 0.0);
         if (R.enabled) {
             R.enabled = false;
             (void)hipStreamSynchronize(p->stream);
@@ -657,12 +771,80 @@ int resident_enable(pipe_hip_processor *p, double value)
     }
     R.idle_ms = value > 1.0 ? (int)value : 250;  // (a value above 1: the idle limit in milliseconds)
     if (R.enabled)
-        return PIPE_HIP_OK;
+        return R.shared ? PIPE_HIP_EBUSY : PIPE_HIP_OK;  // (a sharer: leave the shared queue first)
     PH_TRY(resident_acquire(p));  // PIPE_HIP_EBUSY: another handle of this device holds the doorbell
     PH_HIP(hipStreamSynchronize(p->stream));  // (the two streams trade places with nothing in flight on either)
     R.own_stream = p->stream;
     p->stream = resident_stream(p->cfg.device);
     R.failed = false;
+    R.enabled = true;
+    return PIPE_HIP_OK;
+}
+// PIPE_HIP_PARAM_RESIDENT_SHARED on / off (the handle's entry has run: nothing of the device is parked)
+int resident_enable_shared(pipe_hip_processor *p, double value)
+{
+    pipe_hip_processor::Resident &R = p->resident;
+    const int d = p->cfg.device;
+    if (d < 0 || d >= kMaxDevices)
+        return PIPE_HIP_EINVAL;
+    Door &D = g_door[d];
+    if (value == 0.0) {
+        if (R.enabled && R.shared) {
+            {
+                QmuHold hold(D, d);
+                PH_TRY(shared_cancel_all_locked(D));
+            }
+            (void)hipStreamSynchronize(p->stream);
+            QmuHold hold(D, d);  // (lock order: the queue's lock, then g_door_mu; whoever holds g_door_mu only TRIES the queue's)
+            std::lock_guard<std::mutex> lk(g_door_mu);
+            D.sharers.erase(std::remove(D.sharers.begin(), D.sharers.end(), p), D.sharers.end());
+            R.enabled = R.shared = false;
+            if (R.own_stream) {
+                p->stream = R.own_stream;
+                R.own_stream = nullptr;
+            }
+        }
+        return PIPE_HIP_OK;
+    }
+    if (R.enabled)
+        return R.shared ? PIPE_HIP_OK : PIPE_HIP_EBUSY;  // (it holds the doorbell alone: give that back first)
+    const size_t bytes = dtype_size(p->cfg.dtype) * (size_t)p->cfg.buffer_size * (size_t)p->cfg.channels * (size_t)p->cfg.lines;
+    if (p->owned_by_chain || !p->armable() || !p->fixed_rate() || !p->single_input() || bytes > ((size_t)1 << 20) || p->in_flight)
+        return PIPE_HIP_EINVAL;
+    // (a stage whose full buffers would run the plain path -- a float64 biquad without PIPE_HIP_PARAM_RELAXED_F64: the
+    // ordered recurrence cannot be taken back -- would empty the whole queue at every call: it stays outside)
+    if (!p->armable_for(p->cfg.buffer_size, p->cfg.dtype))
+        return PIPE_HIP_EINVAL;
+    PH_TRY(p->ensure_staging(0));
+    if (!p->stg[0].hd_in || !p->stg[0].hd_out)
+        return PIPE_HIP_EINVAL;
+    if (!R.mail.p) {
+        PH_TRY(R.mail.alloc(128, true));
+        std::memset(R.mail.p, 0, 128);
+    }
+    R.idle_ms = value > 1.0 ? (int)value : 250;
+    {
+        std::lock_guard<std::mutex> lk(g_door_mu);
+        if (D.owner || D.sharers.size() >= kMaxSharers)
+            return PIPE_HIP_EBUSY;
+        PH_TRY(door_prepare(d));
+    }
+    {
+        // (a handle that joins: whatever the others have parked is taken back first -- the streams trade places with
+        // nothing in flight, and this handle's first entry goes to the queue's tail like everybody's)
+        QmuHold hold(D, d);
+        PH_TRY(shared_cancel_all_locked(D));
+    }
+    PH_HIP(hipStreamSynchronize(p->stream));
+    QmuHold hold(D, d);
+    std::lock_guard<std::mutex> lk(g_door_mu);
+    if (D.owner || D.sharers.size() >= kMaxSharers)
+        return PIPE_HIP_EBUSY;
+    D.sharers.push_back(p);
+    R.own_stream = p->stream;
+    p->stream = D.stream;
+    R.failed = false;
+    R.shared = true;
     R.enabled = true;
     return PIPE_HIP_OK;
 }
@@ -693,7 +875,9 @@ pipe_hip_processor::~pipe_hip_processor()
         (void)hipSetDevice(cfg.device);
     if (resident.mail.p) {
         (void)resident_cancel(this);
-        if (resident.enabled)
+        if (resident.enabled && resident.shared)
+            (void)resident_enable_shared(this, 0.0);
+        else if (resident.enabled)
             (void)resident_enable(this, 0.0);  // (the handle's own stream back in `stream`, the doorbell free again)
     }
     // (the frees below wait for every queue of the device: another handle's queued work is rung first, as a mutation
@@ -1225,7 +1409,92 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
     }
     // (a stage whose form depends on the call's size -- the biquad: the tile form can be taken back, the ordered
     // recurrence cannot -- says per call whether its launch may be queued ahead; if not, the plain path below)
-    if (p->resident.enabled && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
+    if (p->resident.enabled && p->resident.shared && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
+        in_frames <= out_cap_frames && !p->resident.failed && p->armable_for(in_frames, p->cfg.dtype)) {
+        // PIPE_HIP_PARAM_RESIDENT_SHARED: the buffer's work waits in the device's ONE doorbell queue, normally at its head
+        // (the handles are called in the order they were called last time: run.go:112-132).  Whatever lies ahead of it
+        // is rung first -- other handles' work, run on stale input and taken back by them -- then its own doorbell; the
+        // successor goes to the queue's tail while this buffer runs.
+        pipe_hip_processor::Resident &R = p->resident;
+        using RS = pipe_hip_processor::Resident;
+        PH_TRY(p->select_device());
+        Door &D = g_door[p->cfg.device];
+        QmuHold hold(D, p->cfg.device);
+        D.last_call = std::chrono::steady_clock::now();
+        const int st = R.state.load(std::memory_order_acquire);
+        if (st == RS::kStale || (st == RS::kArmed && R.frames != in_frames)) {
+            if (st == RS::kArmed) {  // (a short buffer, pipe.go:441-443: the queued work was made for another frame count)
+                (void)shared_ring_through(D, p);
+                R.dropped_by_entry.fetch_add(1, std::memory_order_relaxed);
+            }
+            const int rcw = resident_wait(p, R.seq);
+            R.state.store(RS::kIdle, std::memory_order_release);
+            PH_TRY(rcw);
+            p->rollback_launch();
+        }
+        bool plain = false;
+        if (R.state.load() == RS::kIdle && !D.order.empty()) {
+            // Nothing of this handle is queued (its first call, or its work was taken back) and OTHER handles' work is:
+            // queued now, this buffer's work would sit BEHIND theirs, and ringing them to get at it would cost each of
+            // them a launch -- every handle's first round would knock out its predecessor's successor, for ever.  This
+            // one buffer runs on the handle's own stream instead (nothing parked there), and its successor takes its
+            // place at the queue's tail: after one round of such calls the queue is in the callers' order.
+            pipe_hip_processor::Staging &g = p->stg[0];
+            const size_t es = dtype_size(p->cfg.dtype);
+            std::memcpy(g.h_in.p, in, es * (size_t)in_frames * (size_t)p->cfg.channels * (size_t)p->cfg.lines);
+            int64_t produced = in_frames;
+            PH_TRY(p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, in_frames, &produced, R.own_stream));
+            PH_HIP(hipStreamSynchronize(R.own_stream));
+            bool reran = false;
+            PH_TRY(p->settle(R.own_stream, &reran));
+            std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
+            if (out_frames)
+                *out_frames = (int32_t)produced;
+            const int rc_next = resident_arm(p, in_frames);
+            if (rc_next == PIPE_HIP_OK)
+                D.order.push_back(p);
+            return rc_next == kResidentUnsupported ? PIPE_HIP_OK : rc_next;
+        }
+        if (R.state.load() == RS::kIdle) {  // the queue is empty: this buffer's work at its head
+            const int rc0 = resident_arm(p, in_frames);
+            if (rc0 == kResidentUnsupported) {
+                plain = true;  // no stream memory operations here: the plain path from now on
+            } else {
+                PH_TRY(rc0);
+                D.order.push_back(p);
+            }
+        }
+        if (!plain) {
+            pipe_hip_processor::Staging &g = p->stg[0];
+            const size_t es = dtype_size(p->cfg.dtype);
+            std::memcpy(g.h_in.p, in, es * (size_t)in_frames * (size_t)p->cfg.channels * (size_t)p->cfg.lines);
+            const unsigned k = R.seq;
+            const int64_t produced = R.out_frames;
+            (void)shared_ring_through(D, p);
+            R.state.store(RS::kIdle, std::memory_order_release);  // (rung by its own call: running)
+            int rc_next = resident_arm(p, in_frames);
+            if (rc_next == PIPE_HIP_OK)
+                D.order.push_back(p);
+            else if (rc_next == kResidentUnsupported)
+                rc_next = PIPE_HIP_EHIP;
+            PH_TRY(resident_wait(p, k));
+            if (p->take_failure_flag()) {  // (as on the exclusive path: launch k failed and its successor is queued on its state)
+                (void)shared_cancel_all_locked(D);
+                (void)p->take_failure_flag();
+                R.failed = true;
+                return PIPE_HIP_EHIP;
+            }
+            std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
+            if (out_frames)
+                *out_frames = (int32_t)produced;
+            return rc_next;
+        }
+        hold.lk.unlock();
+        t_holds_qmu = hold.prev;
+        (void)resident_enable_shared(p, 0.0);
+        goto plain_path;
+    }
+    if (p->resident.enabled && !p->resident.shared && in && out && in_frames > 0 && in_frames <= p->cfg.buffer_size &&
         in_frames <= out_cap_frames && !p->resident.failed && p->armable_for(in_frames, p->cfg.dtype)) {
         // The buffer's work is already on the device, behind the doorbell (queued while the last buffer ran):
         // copy in, ring, queue the NEXT buffer's work while this one runs, spin on the completion word.
@@ -1615,6 +1884,11 @@ int pipe_hip_set_param(pipe_hip_processor *p, int32_t param, const double *value
         if (count != 1)
             return PIPE_HIP_EINVAL;
         return resident_enable(p, values[0]);  // (enter() has taken back what was queued)
+    }
+    if (param == PIPE_HIP_PARAM_RESIDENT_SHARED) {
+        if (count != 1)
+            return PIPE_HIP_EINVAL;
+        return resident_enable_shared(p, values[0]);
     }
     return p->set_param(param, values, count);
 }

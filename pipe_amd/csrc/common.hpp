@@ -422,6 +422,9 @@ struct pipe_hip_processor {
         std::vector<pipehip::DeferredFree> frees;     // allocations replaced while work was being queued (freed at the next entry)
         hipStream_t own_stream = nullptr;             // the handle's ordinary stream while `stream` is the device's doorbell stream
         bool failed = false;          // a queued launch failed on the device: the state is unknown until the next StartFunc
+        // PIPE_HIP_PARAM_RESIDENT_SHARED (round 6): the handle is one of SEVERAL that queue their next buffer's work on the
+        // device's one doorbell queue, in the order they are called (abi.hip: the device's queue lock stands for `mu`)
+        bool shared = false;
         unsigned *bell() const { return static_cast<unsigned *>(mail.p); }
         unsigned *done() const { return static_cast<unsigned *>(mail.p) + 16; }
     };

@@ -78,6 +78,13 @@ error finish(pipe_hip_processor *raw, const SignalProperties &input, Processor *
         if (on != 0.0)
             (void)pipe_hip_set_param(raw, PIPE_HIP_PARAM_RESIDENT, &on, 1);
     }
+    // PIPE_HOST_RESIDENT_SHARED: every such stage joins its device's SHARED doorbell queue instead
+    // (PIPE_HIP_PARAM_RESIDENT_SHARED: what a synchronous pipe.Run would ask for -- all Lines in one goroutine, round-robin)
+    if (const char *e = std::getenv("PIPE_HOST_RESIDENT_SHARED")) {
+        const double on = std::atof(e);
+        if (on != 0.0)
+            (void)pipe_hip_set_param(raw, PIPE_HIP_PARAM_RESIDENT_SHARED, &on, 1);
+    }
     int32_t ch = 0, up = 1, down = 1;
     if (error e = StatusError(pipe_hip_output_properties(raw, &ch, &up, &down), "output_properties"))
         return e;

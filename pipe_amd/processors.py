@@ -306,6 +306,17 @@ class Processor:
         L.check(st, "set_param(RESIDENT)")
         return True
 
+    def set_resident_shared(self, on: bool = True, idle_ms: int = 0) -> bool:
+        """PIPE_HIP_PARAM_RESIDENT_SHARED: as set_resident, for SEVERAL handles of one device that are called in a fixed
+        rotation and never concurrently (pipe.Run's synchronous executor): they share the device's one doorbell queue.
+        False when the device's doorbell is held exclusively, or sixteen handles share it already (PIPE_HIP_EBUSY)."""
+        v = np.ascontiguousarray([float(idle_ms) if (on and idle_ms > 1) else (1.0 if on else 0.0)], dtype=np.float64)
+        st = L.lib().pipe_hip_set_param(self._h, L.PARAM_RESIDENT_SHARED, _dptr(v), 1)
+        if st == L.EBUSY:
+            return False
+        L.check(st, "set_param(RESIDENT_SHARED)")
+        return True
+
     def resident_info(self):
         """(holds the doorbell, queued launches dropped by the watchdog, ... dropped by another entry)"""
         held, wd, en = C.c_int32(), C.c_int64(), C.c_int64()

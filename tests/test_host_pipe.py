@@ -194,6 +194,23 @@ def test_hip_processor_error_surfaces_as_run_error():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
+def test_the_host_loop_with_every_stage_sharing_the_doorbell_queue(mode):
+    """The same host-loop tests with every HIP stage in the device's SHARED doorbell queue (PIPE_HIP_PARAM_RESIDENT_SHARED)
+    -- in the synchronous mode it is made for, and in the asynchronous one (a thread per component: calls in any order
+    and concurrent; they serialise on the queue's lock and ring each other's work: slower, and the same bits)."""
+    from tests._child import run_child
+    run_child(f"""
+        import tests.test_host_pipe as T
+        T.test_hip_copy_in_the_loop_config1({mode})
+        T.test_hip_fir_biquad_gain_lines_equal_oracle_loop({mode})
+        T.test_hip_fused_chain_equals_separate_stages_and_oracle()
+        T.test_mutation_reaches_hip_handle_through_the_message()
+        T.test_hip_processor_error_surfaces_as_run_error()
+    """, timeout_s=120, env={"PIPE_HOST_RESIDENT_SHARED": "1"})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
 def test_the_host_loop_through_the_resident_path(mode):
     """run.go:198-224's loop with PIPE_HIP_PARAM_RESIDENT asked for by EVERY HIP stage (the harness's
     PIPE_HOST_RESIDENT is what hip.Stage.SetResident is in the Go shim): the first stage of the device that can take a
@@ -247,6 +264,41 @@ def test_many_lines_of_resident_stages_async_stress():
         print(f"worst run {worst:.2f} s", flush=True)
     """, timeout_s=280, env={"PIPE_HOST_RESIDENT": "1"})
     assert "worst run" in out
+
+
+@pytest.mark.gpu
+def test_the_synchronous_host_loop_with_every_stage_in_the_shared_doorbell_queue():
+    """pipe.Run's synchronous executor (run.go:37-52, 112-132: all Lines in one thread, round-robin, a Line's stages in
+    order) with EVERY HIP stage of 8 Lines in the device's shared doorbell queue (PIPE_HIP_PARAM_RESIDENT_SHARED; the
+    harness's PIPE_HOST_RESIDENT_SHARED): the oracle's loop bit for bit, Lines that end at different times (EOF removal
+    changes the call order: the queue follows), a short last buffer, a restart."""
+    from tests._child import run_child
+    out = run_child("""
+        import time
+        import numpy as np
+        from oracle import oracle as O
+        from pipe_amd import host as H
+        from pipe_amd import synth
+        BUF, LINES = 512, 8
+        taps = synth.fir_lowpass_taps(32)
+        lens = [600 * BUF - 77, 400 * BUF, 600 * BUF + 5, 100 * BUF, 601 * BUF, 7, 300 * BUF - 1, 600 * BUF]
+        mk = lambda i: dict(limit=lens[i], channels=2, src_kind=H.SRC_SYNTH, seed=synth.line_seed(i), discard=False)
+        olines = [O.Line(limit=lens[i], channels=2, src_kind=O.SRC_SYNTH, seed=synth.line_seed(i), discard=False,
+                         procs=[O.Proc(O.PROC_FIR, taps), O.Proc(O.PROC_GAIN, [0.5])]) for i in range(LINES)]
+        oerr, ores = O.run_lines(BUF, olines)
+        for rep in range(3):
+            hlines = [H.Line(procs=[H.Proc(H.PROC_HIP_FIR, taps), H.Proc(H.PROC_HIP_GAIN, [0.5])], **mk(i)) for i in range(LINES)]
+            t0 = time.perf_counter()
+            herr, hres = H.run(BUF, hlines, H.MODE_RUN)
+            dt = time.perf_counter() - t0
+            assert not herr.failed, herr.message
+            for h, o in zip(hres, ores):
+                assert (h.sink.messages, h.sink.samples) == (o.sink.messages, o.sink.samples)
+                assert np.array_equal(h.values, o.values), rep
+            calls = sum(r.sink.messages for r in hres) * 2
+            print(f"run {rep}: {dt:.2f} s, {dt / calls * 1e6:.1f} us per stage call", flush=True)
+    """, timeout_s=200, env={"PIPE_HOST_RESIDENT_SHARED": "1"})
+    assert "us per stage call" in out
 
 
 # ---------------------------------------------------------- stage-major (batched) Run
