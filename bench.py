@@ -1010,6 +1010,36 @@ def run_rank(args, rank, world, local, sync, launch):
                 "kernel": kng, "avg_kernel_ms": round(msg, 5), "algorithmic_bytes_per_launch": 2 * ng * 4,
                 "roofline_frac": round(2 * ng * 4 / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
+        # ---- configs[1] as the reference runs it: ONE 4096 x 2 buffer per ProcessFunc call (latency-bound, never `value`) ----
+        # 8 FIR handles (8 Lines' stages) called round-robin -- the synchronous host loop's order, run.go:112-132 -- on the
+        # plain path, with the device's doorbell held by one of them, and all of them in the SHARED doorbell queue
+        # (PIPE_HIP_PARAM_RESIDENT_SHARED); through ctypes (a C caller: ~4 us less a call, examples/percall_latency.c)
+        pc = {}
+        xb = np.ascontiguousarray(synth.samples(synth.line_seed(5), 0, F * C).reshape(F, C).astype(np_dtype))
+        for mode_pc in ("plain", "exclusive_doorbell", "shared_doorbell_queue"):
+            hs = [P.Fir(taps, F, C, dtype=np_dtype, device=local) for _ in range(8)]
+            for h in hs:
+                h.start()
+                if mode_pc == "exclusive_doorbell":
+                    h.set_resident(True)
+                elif mode_pc == "shared_doorbell_queue":
+                    h.set_resident_shared(True)
+            for _ in range(10):
+                for h in hs:
+                    h.process(xb)
+            tt = []
+            for _ in range(150):
+                for h in hs:
+                    t0 = time.perf_counter()
+                    h.process(xb)
+                    tt.append(time.perf_counter() - t0)
+            tt.sort()
+            pc[mode_pc] = {"median_us": round(tt[len(tt) // 2] * 1e6, 2), "p90_us": round(tt[len(tt) * 9 // 10] * 1e6, 2)}
+            for h in hs:
+                h.close()
+        pc["workload"] = f"8 handles x one {F} x {C} {args.dtype} buffer per pipe_hip_process call, {N}-tap FIR, round-robin, 1200 calls each mode"
+        result["per_call"] = pc
+
         # ---- what a rank's share costs (one GPU; no multi-GPU hardware is needed for this) ---------------------
         # configs[3] / configs[2] deal their Lines to G ranks: rank r runs total / G Lines.  t(L) below is one
         # launch over L Lines on THIS GPU (streaming sets); the projected speed-up of G GPUs is

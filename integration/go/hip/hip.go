@@ -427,6 +427,33 @@ func (s *Stage) SetResident(on bool, idle time.Duration) mutable.Mutation {
 	})
 }
 
+// SetResidentShared puts the stage into its device's SHARED doorbell queue (PIPE_HIP_PARAM_RESIDENT_SHARED, round 6): up to
+// sixteen stages of a device each keep their next buffer's work queued at the tail of ONE hardware queue, in the order
+// they are called.  That order is the order of the last round exactly when the pipe runs its Lines synchronously --
+// pipe.Run: all Lines of a mutable context in one goroutine, round-robin, a Line's stages in order (run.go:37-52,
+// 112-132) -- and then EVERY stage of EVERY Line has the doorbell's latency (a 256-tap FIR call 20 us through a binding
+// where the plain path takes 24 - 30 with 2 - 16 stages on the device).  In the asynchronous mode (pipe.New + Start: a
+// goroutine per component) calls arrive in any order, ring each other's queued work and cost MORE than the plain path
+// (27 against 12 us in the probe): use SetResident on the one busiest stage there.  ErrDoorbellBusy when a stage holds
+// the device's doorbell exclusively or sixteen share it already.  Bit for bit the plain path's results.
+func (s *Stage) SetResidentShared(on bool, idle time.Duration) mutable.Mutation {
+	v := 0.0
+	if on {
+		v = 1
+		if ms := float64(idle / time.Millisecond); ms > 1 {
+			v = ms
+		}
+	}
+	return s.mctx.Mutate(func() error {
+		d := C.double(v)
+		st := C.pipe_hip_set_param(s.p, C.PIPE_HIP_PARAM_RESIDENT_SHARED, &d, 1)
+		if st == C.PIPE_HIP_EBUSY {
+			return ErrDoorbellBusy
+		}
+		return status(st, "set resident shared")
+	})
+}
+
 // ErrDoorbellBusy: another stage of the device holds the doorbell; this one keeps the plain path.
 var ErrDoorbellBusy = errors.New("pipe_hip: the device's doorbell is held by another stage")
 
