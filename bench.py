@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--power-window", type=float, default=2.5, help="seconds of the headline launch under the power sampler")
     ap.add_argument("--no-scale-projection", action="store_true", help="skip the one-GPU measurement of a rank's share (N = 1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config[2]-shape line at N = 1")
+    ap.add_argument("--no-per-call", action="store_true",
+                    help="skip the per_call row (the counter passes do: a profiler that serialises dispatches turns every "
+                         "parked doorbell wait into a watchdog timeout)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 --pmc passes of this command (N = 1)")
     ap.add_argument("--cpu-buffers", type=int, default=4096,
@@ -162,7 +165,7 @@ def live_pmc(args, want):
         return {}
     out = tempfile.mkdtemp(prefix="pipe_bench_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc",
-             "--no-power", "--no-scale-projection",
+             "--no-power", "--no-scale-projection", "--no-per-call",
              "--config", str(args.config), "--frames", str(args.frames), "--taps", str(args.taps), "--dtype", args.dtype]
     for name in ("buffers", "channels", "lines"):
         if getattr(args, name) is not None:
@@ -176,7 +179,18 @@ def live_pmc(args, want):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             cmd = ["timeout", "-k", "5", "90", "rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            # (a session of its own: a pass that overruns is ended WITH its grandchildren -- a profiled child left behind
+            # would share the GPU with everything timed after it)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=100)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)
+                except OSError:
+                    pass
+                pr.wait()
+                raise
             per = {}
             for p in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                 db = sqlite3.connect(p)
@@ -1016,7 +1030,7 @@ def run_rank(args, rank, world, local, sync, launch):
         # (PIPE_HIP_PARAM_RESIDENT_SHARED); through ctypes (a C caller: ~4 us less a call, examples/percall_latency.c)
         pc = {}
         xb = np.ascontiguousarray(synth.samples(synth.line_seed(5), 0, F * C).reshape(F, C).astype(np_dtype))
-        for mode_pc in ("plain", "exclusive_doorbell", "shared_doorbell_queue"):
+        for mode_pc in (() if args.no_per_call else ("plain", "exclusive_doorbell", "shared_doorbell_queue")):
             hs = [P.Fir(taps, F, C, dtype=np_dtype, device=local) for _ in range(8)]
             for h in hs:
                 h.start()
@@ -1038,7 +1052,8 @@ def run_rank(args, rank, world, local, sync, launch):
             for h in hs:
                 h.close()
         pc["workload"] = f"8 handles x one {F} x {C} {args.dtype} buffer per pipe_hip_process call, {N}-tap FIR, round-robin, 1200 calls each mode"
-        result["per_call"] = pc
+        if not args.no_per_call:
+            result["per_call"] = pc
 
         # ---- what a rank's share costs (one GPU; no multi-GPU hardware is needed for this) ---------------------
         # configs[3] / configs[2] deal their Lines to G ranks: rank r runs total / G Lines.  t(L) below is one

@@ -1,6 +1,7 @@
 """bench.py's one JSON line: the fields the driver and the judge read (a short run, bounded CPU legs)."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -13,11 +14,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run_bench(*args, env=None):
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     e.update(env or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, capture_output=True,
-                         text=True, timeout=900, env=e)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]          # exactly ONE JSON line
+    # a session of its own, ended as a group whatever happens: a bench run cut short by the per-test limit must not
+    # leave its counter passes (rocprofv3 grandchildren) on the GPU under the tests that follow
+    pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, env=e, start_new_session=True)
+    try:
+        stdout, stderr = pr.communicate(timeout=900)
+    finally:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+    assert pr.returncode == 0, stderr[-2000:]
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]          # exactly ONE JSON line
     return json.loads(lines[0])
 
 
