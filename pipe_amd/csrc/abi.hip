@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <functional>
@@ -437,6 +438,92 @@ thread_local int t_holds_qmu = -1;  // device whose qmu the calling thread holds
 std::mutex &g_door_mu = *new std::mutex;  // guards g_door[].owner; lock order: g_door_mu, then TRY a handle's resident.mu
 Door *g_door = new Door[kMaxDevices];
 
+// ---- PIPE_HIP_STALL_DUMP_MS=<ms>: where every thread inside the library stands, printed by the watchdog when one of
+// them has stood in the same place for that long (a debugging aid for hangs that only a GPU box shows: no debugger
+// there).  Markers are two relaxed stores each; without the variable nothing is ever printed.
+struct StallSlot {
+    std::atomic<const char *> at{nullptr};
+    std::atomic<const void *> who{nullptr};
+    std::atomic<long long> since_us{0};
+};
+constexpr int kStallSlots = 256;
+StallSlot *g_stall = new StallSlot[kStallSlots];
+std::atomic<int> g_stall_used{0};
+thread_local StallSlot *t_stall = nullptr;
+inline long long stall_now_us()
+{
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct At {  // RAII marker: "this thread is at `name` on behalf of handle `who`"; nests
+    const char *prev_at = nullptr;
+    const void *prev_who = nullptr;
+    long long prev_since = 0;
+    At(const char *name, const void *who)
+    {
+        if (!t_stall) {
+            const int i = g_stall_used.fetch_add(1, std::memory_order_relaxed);
+            t_stall = &g_stall[i < kStallSlots ? i : kStallSlots - 1];
+        }
+        prev_at = t_stall->at.load(std::memory_order_relaxed);
+        prev_who = t_stall->who.load(std::memory_order_relaxed);
+        prev_since = t_stall->since_us.load(std::memory_order_relaxed);
+        t_stall->who.store(who, std::memory_order_relaxed);
+        t_stall->since_us.store(stall_now_us(), std::memory_order_relaxed);
+        t_stall->at.store(name, std::memory_order_release);
+    }
+    ~At()
+    {
+        t_stall->who.store(prev_who, std::memory_order_relaxed);
+        t_stall->since_us.store(prev_since, std::memory_order_relaxed);
+        t_stall->at.store(prev_at, std::memory_order_release);
+    }
+};
+void stall_report_if_stuck()  // (the watchdog thread, g_door_mu held)
+{
+    static const long long limit_us = [] {
+        const char *e = std::getenv("PIPE_HIP_STALL_DUMP_MS");
+        return e ? std::atoll(e) * 1000 : 0LL;
+    }();
+    static int dumps = 0;
+    static long long last = 0;
+    if (limit_us <= 0 || dumps >= 6)
+        return;
+    const long long now = stall_now_us();
+    if (now - last < 2000000)
+        return;
+    bool stuck = false;
+    const int n = std::min(g_stall_used.load(), kStallSlots);
+    for (int i = 0; i < n; ++i)
+        if (g_stall[i].at.load(std::memory_order_acquire) && now - g_stall[i].since_us.load() > limit_us)
+            stuck = true;
+    if (!stuck)
+        return;
+    last = now;
+    ++dumps;
+    std::fprintf(stderr, "[pipe_hip stall] ---- dump %d ----\n", dumps);
+    for (int i = 0; i < n; ++i)
+        if (const char *a = g_stall[i].at.load(std::memory_order_acquire))
+            std::fprintf(stderr, "[pipe_hip stall] thread slot %d: %s (handle %p) for %.1f ms\n", i, a, g_stall[i].who.load(),
+                         (now - g_stall[i].since_us.load()) / 1000.0);
+    for (int d = 0; d < kMaxDevices; ++d) {
+        Door &D = g_door[d];
+        if (!D.owner && D.sharers.empty())
+            continue;
+        std::unique_lock<std::mutex> ql(*D.qmu, std::try_to_lock);
+        std::fprintf(stderr, "[pipe_hip stall] device %d: owner %p, %zu sharers, queue lock %s, ms since the last shared call %.1f\n", d,
+                     (void *)D.owner, D.sharers.size(), ql.owns_lock() ? "free" : "HELD",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - D.last_call).count());
+        for (pipe_hip_processor *q : D.sharers)  // (racy reads when the lock is held by somebody: a debugging aid)
+            std::fprintf(stderr, "[pipe_hip stall]   sharer %p: state %d seq %u bell %u done %u frames %d\n", (void *)q,
+                         q->resident.state.load(), q->resident.seq, q->resident.mail.p ? *q->resident.bell() : 0u,
+                         q->resident.mail.p ? *q->resident.done() : 0u, (int)q->resident.frames);
+        if (ql.owns_lock())
+            for (pipe_hip_processor *q : D.order)
+                std::fprintf(stderr, "[pipe_hip stall]   queued: %p\n", (void *)q);
+    }
+    std::fflush(stderr);
+}
+
 // Wait for a word in coherent pinned memory to become k: pause-spin for the length of a per-buffer kernel, then
 // yield the core, then sleep in 50 us steps (a host core spins per call in flight, for at most ~50 us).
 bool wait_word(const unsigned *w, unsigned k, std::chrono::milliseconds limit)
@@ -462,13 +549,26 @@ bool wait_word(const unsigned *w, unsigned k, std::chrono::milliseconds limit)
     }
 }
 
+// The stream a handle's queued work sits on.  The exclusive holder of the doorbell runs EVERYTHING on the device's doorbell
+// stream (`stream` is that stream while it holds the doorbell: nobody else ever parks anything there).  A sharer keeps
+// its own stream in `stream` for everything but its queued work: whatever blocks on the shared stream outside the
+// queue's lock -- the hipStreamSynchronize of pipe_hip_start / pipe_hip_flush / drain() -- waits behind other handles'
+// parked doorbells WHILE HOLDING THE RUNTIME'S LOCK ON THAT STREAM, and the handle that could ring them (it holds the
+// queue's lock, so the watchdog cannot) then blocks in its own next launch onto the stream: seen as 2 hangs in 6 runs of
+// the async host loop (a thread per component; profiles/r06_shared_queue_async_hang.txt).
+hipStream_t queue_stream(const pipe_hip_processor *p)
+{
+    return p->resident.shared ? g_door[p->cfg.device].stream : p->stream;
+}
 // the completion word of doorbell k (the bell HAS been rung: the stream cannot wait for anything of ours any more)
 int resident_wait(pipe_hip_processor *p, unsigned k)
 {
+    At at("resident_wait: the completion word", p);
     if (wait_word(p->resident.done(), k, std::chrono::milliseconds(10000)))
         return PIPE_HIP_OK;
     // ten seconds: a device busy with somebody else's work, or gone.  The runtime's own wait ends either way.
-    if (hipStreamSynchronize(p->stream) != hipSuccess) {
+    At at2("resident_wait: 10 s over, hipStreamSynchronize(queue_stream)", p);
+    if (hipStreamSynchronize(queue_stream(p)) != hipSuccess) {
         g_last_hip_error = (int)hipGetLastError();
         return PIPE_HIP_EHIP;
     }
@@ -515,7 +615,8 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
     pipe_hip_processor::Resident &R = p->resident;
     pipe_hip_processor::Staging &g = p->stg[0];
     const unsigned k = R.seq + 1;
-    if (hipStreamWaitValue32(p->stream, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) {
+    const hipStream_t qs = queue_stream(p);
+    if (hipStreamWaitValue32(qs, R.bell(), k, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) {
         (void)hipGetLastError();  // (a platform without stream memory operations: nothing was queued)
         return kResidentUnsupported;
     }
@@ -528,11 +629,11 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
     int64_t out_frames = frames;
     g_deferred_frees = &R.frees;
     p->queued_run = true;
-    const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, p->stream);
+    const int rc = p->run_var(g.hd_in, p->cfg.dtype, frames, g.hd_out, p->cfg.dtype, frames, &out_frames, qs);
     p->queued_run = false;
     g_deferred_frees = nullptr;
     R.out_frames = out_frames;
-    const hipError_t we = hipStreamWriteValue32(p->stream, R.done(), k, 0);
+    const hipError_t we = hipStreamWriteValue32(qs, R.done(), k, 0);
     if (we != hipSuccess || rc != PIPE_HIP_OK) {
         // the queued work is incomplete (or no completion word will be written for k): release the wait now, drain the
         // stream the slow way and take back whatever part of the launch was queued
@@ -541,7 +642,7 @@ int resident_arm(pipe_hip_processor *p, int32_t frames)
         if (R.shared)
             shared_ring_all(g_door[p->cfg.device], false);  // (other handles' work ahead of ours in the queue: the stream could not drain)
         __atomic_store_n(R.bell(), k, __ATOMIC_RELEASE);
-        (void)hipStreamSynchronize(p->stream);
+        (void)hipStreamSynchronize(qs);  // (shared: everything parked has been rung, and the queue's lock is held)
         __atomic_store_n(R.done(), k, __ATOMIC_RELEASE);  // (what the missing store would have written)
         p->rollback_launch();
         R.state.store(pipe_hip_processor::Resident::kIdle, std::memory_order_release);
@@ -595,7 +696,14 @@ int shared_cancel_all_locked(Door &D)
 struct QmuHold {  // the device's queue lock, and the note that this thread holds it
     std::unique_lock<std::mutex> lk;
     int prev;
-    explicit QmuHold(Door &D, int device) : lk(*D.qmu), prev(t_holds_qmu) { t_holds_qmu = device; }
+    explicit QmuHold(Door &D, int device) : lk(*D.qmu, std::defer_lock), prev(t_holds_qmu)
+    {
+        {
+            At at("waiting for the device's queue lock", nullptr);
+            lk.lock();
+        }
+        t_holds_qmu = device;
+    }
     ~QmuHold() { t_holds_qmu = prev; }
 };
 int resident_cancel(pipe_hip_processor *p)
@@ -667,6 +775,7 @@ void resident_watchdog()
     for (;;) {
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
         std::lock_guard<std::mutex> lk(g_door_mu);
+        stall_report_if_stuck();
         for (int d = 0; d < kMaxDevices; ++d) {
             if (pipe_hip_processor *o = g_door[d].owner)
                 resident_ring_foreign(o, true, true);
@@ -794,15 +903,14 @@ int resident_enable_shared(pipe_hip_processor *p, double value)
                 QmuHold hold(D, d);
                 PH_TRY(shared_cancel_all_locked(D));
             }
-            (void)hipStreamSynchronize(p->stream);
+            {
+                At at("leaving the shared queue: hipStreamSynchronize(p->stream)", p);
+                (void)hipStreamSynchronize(p->stream);
+            }
             QmuHold hold(D, d);  // (lock order: the queue's lock, then g_door_mu; whoever holds g_door_mu only TRIES the queue's)
             std::lock_guard<std::mutex> lk(g_door_mu);
             D.sharers.erase(std::remove(D.sharers.begin(), D.sharers.end(), p), D.sharers.end());
             R.enabled = R.shared = false;
-            if (R.own_stream) {
-                p->stream = R.own_stream;
-                R.own_stream = nullptr;
-            }
         }
         return PIPE_HIP_OK;
     }
@@ -835,14 +943,15 @@ int resident_enable_shared(pipe_hip_processor *p, double value)
         QmuHold hold(D, d);
         PH_TRY(shared_cancel_all_locked(D));
     }
-    PH_HIP(hipStreamSynchronize(p->stream));
+    {
+        At at("joining the shared queue: hipStreamSynchronize(p->stream)", p);
+        PH_HIP(hipStreamSynchronize(p->stream));
+    }
     QmuHold hold(D, d);
     std::lock_guard<std::mutex> lk(g_door_mu);
     if (D.owner || D.sharers.size() >= kMaxSharers)
         return PIPE_HIP_EBUSY;
-    D.sharers.push_back(p);
-    R.own_stream = p->stream;
-    p->stream = D.stream;
+    D.sharers.push_back(p);  // (`stream` stays the handle's own: queue_stream())
     R.failed = false;
     R.shared = true;
     R.enabled = true;
@@ -886,6 +995,7 @@ pipe_hip_processor::~pipe_hip_processor()
         resident_ring_device(cfg.device, this);
     delete overlap;
     if (stream) {
+        At at("destructor: hipStreamSynchronize + hipStreamDestroy", this);
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
     }
@@ -1320,10 +1430,12 @@ int pipe_hip_start(pipe_hip_processor *p)
 {
     if (!p)
         return PIPE_HIP_EINVAL;
+    At at("pipe_hip_start", p);
     PH_TRY(p->enter());
     PH_TRY(p->drain());  // a restarted pipe drops whatever was in flight, on whichever stream
     p->in_flight = 0;
     p->resident.failed = false;
+    At at2("pipe_hip_start: start(p->stream) + hipStreamSynchronize(p->stream)", p);
     PH_TRY(p->start(p->stream));
     PH_HIP(hipStreamSynchronize(p->stream));
     return PIPE_HIP_OK;
@@ -1346,6 +1458,7 @@ int pipe_hip_flush(pipe_hip_processor *p)
 {
     if (!p)
         return PIPE_HIP_EINVAL;
+    At at("pipe_hip_flush", p);
     PH_TRY(p->enter());
     PH_TRY(p->drain());
     p->in_flight = 0;
@@ -1358,6 +1471,7 @@ int pipe_hip_destroy(pipe_hip_processor *p)
         return PIPE_HIP_OK;
     if (p->owned_by_chain)
         return PIPE_HIP_EINVAL;
+    At at("pipe_hip_destroy", p);
     (void)p->enter();   // (its device; its own queued work taken back BEFORE any member is freed: a free waits for every queue)
     (void)p->drain();   // everything the handle has queued anywhere (its own stream, a caller's stream of a batch call)
     resident_ring_device(p->cfg.device, p);  // (another handle's queued work would hold the frees up until its watchdog)
@@ -1419,6 +1533,7 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         using RS = pipe_hip_processor::Resident;
         PH_TRY(p->select_device());
         Door &D = g_door[p->cfg.device];
+        At at("pipe_hip_process: shared queue", p);
         QmuHold hold(D, p->cfg.device);
         D.last_call = std::chrono::steady_clock::now();
         const int st = R.state.load(std::memory_order_acquire);
@@ -1443,10 +1558,11 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
             const size_t es = dtype_size(p->cfg.dtype);
             std::memcpy(g.h_in.p, in, es * (size_t)in_frames * (size_t)p->cfg.channels * (size_t)p->cfg.lines);
             int64_t produced = in_frames;
-            PH_TRY(p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, in_frames, &produced, R.own_stream));
-            PH_HIP(hipStreamSynchronize(R.own_stream));
+            At at3("pipe_hip_process: shared queue: this buffer on the handle's own stream (run_var + sync)", p);
+            PH_TRY(p->run_var(g.hd_in, p->cfg.dtype, in_frames, g.hd_out, p->cfg.dtype, in_frames, &produced, p->stream));
+            PH_HIP(hipStreamSynchronize(p->stream));
             bool reran = false;
-            PH_TRY(p->settle(R.own_stream, &reran));
+            PH_TRY(p->settle(p->stream, &reran));
             std::memcpy(out, g.h_out.p, es * (size_t)produced * (size_t)p->out_channels() * (size_t)p->cfg.lines);
             if (out_frames)
                 *out_frames = (int32_t)produced;
@@ -1547,6 +1663,7 @@ int pipe_hip_process(pipe_hip_processor *p, const void *in, int32_t in_frames, v
         return rc_next;
     }
 plain_path:
+    At at_plain("pipe_hip_process: plain path (submit + collect)", p);
     PH_TRY(submit_impl(p, in, in_frames, out_cap_frames));
     return collect_impl(p, out, out_cap_frames, out_frames);
 }

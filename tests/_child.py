@@ -18,6 +18,8 @@ def run_child(code: str, timeout_s: float = 90.0, env: dict | None = None) -> st
     e = dict(os.environ)
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
     e["PYTHONFAULTHANDLER"] = "1"
+    # (a hang in native code names itself: the library's watchdog prints where every thread stands, abi.hip)
+    e.setdefault("PIPE_HIP_STALL_DUMP_MS", "8000")
     if env:
         e.update(env)
     prog = "import faulthandler, sys; faulthandler.enable()\n" + textwrap.dedent(code) + "\nprint('CHILD-OK', flush=True)\n"
