@@ -14,14 +14,16 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-env $EXTRA_ENV rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py $BENCH_ARGS --no-cpu-baseline --no-secondary --no-live-pmc --no-power > $OUT/trace.json 2> $OUT/trace.err
+env $EXTRA_ENV timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/bench.py $BENCH_ARGS --no-cpu-baseline --no-secondary --no-live-pmc --no-power --no-per-call > $OUT/trace.json 2> $OUT/trace.err
 # PMC_SECONDARY=1: the FETCH / WRITE passes also run the default line's configs[3] / configs[4] objects
 # (c4_chain, c5_resampler_mix), so that their HBM traffic gets an entry too
 pmc() { # name counters...
   local name=$1; shift
   local sec=--no-secondary
   if [ "${PMC_SECONDARY:-0}" = 1 ] && { [ $name = fetch ] || [ $name = write ]; }; then sec=; fi
-  env $EXTRA_ENV rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-live-pmc --no-power --no-scale-projection $sec > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  # (--no-per-call: the per_call row parks doorbell waits that a profiler serialising dispatches turns into watchdog
+  # timeouts, 250 ms a call -- round 6 lost 45 GPU-minutes to it; every pass under its own limit)
+  env $EXTRA_ENV timeout -k 5 400 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-live-pmc --no-power --no-scale-projection --no-per-call $sec > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
 }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SALU

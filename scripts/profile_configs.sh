@@ -8,9 +8,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/scripts/bench_configs.py > $OUT/trace.jsonl 2> $OUT/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $REPO/scripts/bench_configs.py > $OUT/pmc_fetch.jsonl 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $REPO/scripts/bench_configs.py > $OUT/pmc_write.jsonl 2> $OUT/pmc_write.err
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $REPO/scripts/bench_configs.py > $OUT/trace.jsonl 2> $OUT/trace.err
+timeout -k 5 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $REPO/scripts/bench_configs.py > $OUT/pmc_fetch.jsonl 2> $OUT/pmc_fetch.err
+timeout -k 5 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $REPO/scripts/bench_configs.py > $OUT/pmc_write.jsonl 2> $OUT/pmc_write.err
 cd $REPO
 python scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | cut -c1-260

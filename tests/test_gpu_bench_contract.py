@@ -19,7 +19,7 @@ def run_bench(*args, env=None):
     pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, env=e, start_new_session=True)
     try:
-        stdout, stderr = pr.communicate(timeout=900)
+        stdout, stderr = pr.communicate(timeout=400)
     finally:
         try:
             os.killpg(pr.pid, signal.SIGKILL)
@@ -31,6 +31,7 @@ def run_bench(*args, env=None):
     return json.loads(lines[0])
 
 
+@pytest.mark.limit(420)
 def test_default_line_has_every_contract_field():
     d = run_bench("--steps", "3", "--warmup", "1", "--buffers", "4096", "--cpu-buffers", "64")
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
