@@ -808,6 +808,19 @@ def run_rank(args, rank, world, local, sync, launch):
                 "warmup_launches": 300, "timed_launches": 100,
             }
 
+        # SURVEY.md 8(d) "C2" resident shape, to the letter: ONE Line x 256 consecutive buffers (8 MiB in + 8 MiB out).
+        # A launch of this size is over in a few microseconds: what it shows is the launch's ramp (the chip fills and
+        # drains once per 1366 tiles), not the kernel's rate -- reported so that the point exists, never as `value`.
+        K1 = 256
+        n1 = F * K1 * C
+        with P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=1, max_batch=K1) as f1:
+            f1.start()
+            r1, _ = both(f1, n1, n1, F * K1, 200, 300, n1 * bps)
+            r1["workload"] = (f"SURVEY 8d C2: 1 Line x {K1} consecutive buffers x {F} x {C} f32 resident in HBM, one launch per step "
+                              "(launch-bound at this size; the headline is the same Line at 131072 buffers)")
+            r1["msamples_per_s"] = round(n1 / (r1["avg_kernel_ms"] * 1e-3) / 1e6, 1)
+            result["c2_k256"] = r1
+
         # BASELINE configs[3] (SURVEY 8d "C4") at N = 1: 512 Lines x 8 ch x one 4096-frame buffer through
         # FIR-256 -> biquad -> gain as ONE fused kernel; the same launch `--config 3` times
         L4, C4 = 512, 8
@@ -897,6 +910,20 @@ def run_rank(args, rank, world, local, sync, launch):
                 rb["avg_ms"] = rb["avg_kernel_ms"]
                 rb["msamples_per_s"] = round(nb / (rb["avg_kernel_ms"] * 1e-3) / 1e6, 1)
                 bq[tag] = rb
+        # the same kernel once a launch is long enough to forget its edges (16 buffers per Line: 1 GiB in + 1 GiB out,
+        # streaming by its size; the 16.7 M-sample launches above are two rounds of workgroups that load, compute and
+        # store in step)
+        Kbs = 16
+        nbs = 512 * Kbs * F * 8
+        if nbs <= min(ARENA, d_src.numel()):
+            with P.Biquad(synth.biquad_rbj_lowpass(), F, 8, dtype=np_dtype, device=local, lines=512, max_batch=Kbs) as bqp:
+                bqp.start()
+                _, kbs, nlbs, knbs = timed(bqp, 40, 20, d_src[:nbs], arena[:nbs], Kbs * F)
+                msbs = kbs / max(nlbs, 1)
+                bq["steady_state_512x8x16_buffers"] = {
+                    "kernel": knbs, "avg_kernel_ms": round(msbs, 5), "algorithmic_bytes_per_launch": nbs * bps,
+                    "roofline_frac": round(nbs * bps / (msbs * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "msamples_per_s": round(nbs / (msbs * 1e-3) / 1e6, 1)}
         result["biquad_alone"] = bq
 
         # BASELINE configs[4]: the 44.1 -> 48 kHz polyphase resampler (160/147, 24 taps per phase) over
