@@ -809,8 +809,9 @@ def run_rank(args, rank, world, local, sync, launch):
             }
 
         # SURVEY.md 8(d) "C2" resident shape, to the letter: ONE Line x 256 consecutive buffers (8 MiB in + 8 MiB out).
-        # A launch of this size is over in a few microseconds: what it shows is the launch's ramp (the chip fills and
-        # drains once per 1366 tiles), not the kernel's rate -- reported so that the point exists, never as `value`.
+        # 1364 transforms are not one unit for every wave of the chip: the launch is as long as a lone wave's unit
+        # (15 - 16 us, profiles/r06_fir_small_calls.txt), not as the kernel's rate -- reported so that the point
+        # exists, never as `value`.
         K1 = 256
         n1 = F * K1 * C
         with P.Fir(taps, F, C, dtype=np_dtype, device=local, lines=1, max_batch=K1) as f1:

@@ -669,10 +669,14 @@ public:
     }
 
 private:
-    // enough 1024-point transforms to give every SIMD of the chip a few
+    // The overlap-save launch costs 15 - 17 us whatever it carries up to a unit a wave (2048 transforms on 256 CUs: a lone
+    // wave's unit is that long); the ordered form on the matrix pipe starts at 9 us and grows by 5 us per 512 transforms.
+    // They cross between 800 (one long Line) and 1000 transforms (many one-buffer Lines): 4 a CU.  (8 a CU until round
+    // 6 -- measured against the VALU direct form, before the matrix-pipe form existed: calls of 1024 - 2047 transforms
+    // took 19 - 34 us where overlap-save takes 16 - 17, profiles/r06_fir_small_calls.txt.)
     int64_t ols_min_items() const
     {
-        return knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 8 * (int64_t)cus_;
+        return knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 4 * (int64_t)cus_;
     }
 
     // the history of all Lines into the other half of the double buffer in the other element type
