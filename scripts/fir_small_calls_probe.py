@@ -17,6 +17,8 @@ taps = synth.fir_lowpass_taps(N, f32_rounded=True)
 st = torch.cuda.Stream()
 SHAPES = [(1, 8), (1, 16), (1, 32), (1, 64), (1, 96), (1, 128), (1, 192), (1, 256), (1, 384), (1, 512), (1, 1024),
           (8, 1), (16, 1), (32, 1), (64, 1), (128, 1), (256, 1), (512, 1), (64, 4)]
+if os.environ.get("PROBE_SHAPES"):   # "lines,buffers;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["PROBE_SHAPES"].split(";")]
 for lines, K in SHAPES:
     n = lines * K * F * C
     items = lines * -(-K * F // 769) * -(-C // 2)
