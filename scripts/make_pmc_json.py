@@ -84,6 +84,6 @@ if c4:
     entries.append(entry_for(c4["kernel"], r"fir_ols32_kernel<float, float, [12]", c4["workload"], c4["algorithmic_bytes_per_launch"]))
 c5 = (full.get("c5_resampler_mix") or {}).get("resampler")
 if c5:
-    entries.append(entry_for(c5["kernel"], r"resample_(pair|tiled)_kernel<", full["c5_resampler_mix"]["workload"],
+    entries.append(entry_for(c5["kernel"], r"resample_(wave|pair|tiled)_kernel<", full["c5_resampler_mix"]["workload"],
                              c5["algorithmic_bytes_per_launch"]))
 print(json.dumps(entries if len(entries) > 1 else entries[0], indent=1))
