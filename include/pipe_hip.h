@@ -61,8 +61,8 @@ typedef enum pipe_hip_param {
                                   FIR's overlap-save FFT form / the biquad's time-segmented form /
                                   the fused FIR+biquad+gain chain kernel.  Those "relaxed" forms are
                                   chosen by CALL SIZE (large device-resident batches; for the biquad
-                                  also one float32 buffer of 1024 frames or more of at most 64
-                                  series per call -- thresholds in DESIGN.md), so the same stream can
+                                  also float32 buffers of 1024 frames or more a Line in any call --
+                                  thresholds in DESIGN.md), so the same stream can
                                   give different last bits for different call sizes or devices.  Their bound, as tested: the
                                   float64 value differs from the oracle's by O(1e-16) of the filter's
                                   full-scale output, i.e. the float32 result is within one float32

@@ -1327,7 +1327,7 @@ public:
         if (exact_ || env_exact_ || (out_dtype != PIPE_HIP_F32 && !relaxed_f64_) || !relaxed_ok() || windowed() || ext_state_)
             return false;
         const int64_t nseries = (int64_t)cfg.lines * cfg.channels;
-        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && nseries <= kTileLatencySeries;
+        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames;
         return S_ <= kTileMaxSections && cfg.channels <= 8 && (frames * nseries >= seg_min_samples_ || long_few) &&
                frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") && !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS") &&
                !(cfg.channels >= kTileWalkChannels && cfg.lines >= tile_walk_lines_);
@@ -1540,8 +1540,10 @@ public:
         // ProcessFunc call -- is where the ordered recurrence hurts most: it is one wave's issue, 22 ns a frame
         // whatever the chip (4096 x 2: 90 us, a host core does it in 10).  The tile form takes a float32 buffer of
         // kTileLatencyFrames or more frames in one short launch (4096 x 2: 12.8 us); PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES
-        // set in the environment is the only rule when it is there.
-        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames && a.nseries <= kTileLatencySeries;
+        // set in the environment is the only rule when it is there.  (Until round 6 only for up to 64 series: 65 - 255
+        // series of 4096 frames -- 16 Lines x 8 ch, one buffer each -- fell between this rule and the sample count above
+        // and took the ordered form, 86 - 118 us where the tile form takes 9 - 12, profiles/r06_biquad_dispatch_gap.txt.)
+        const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames;
         a.state_out = a.state;
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
                            frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") &&
@@ -2221,7 +2223,7 @@ private:
     size_t state_bytes_ = 0;
     bool exact_ = false;
     const bool env_exact_ = std::getenv("PIPE_HIP_BIQUAD_EXACT") != nullptr;
-    static constexpr int64_t kTileLatencyFrames = 1024, kTileLatencySeries = 64;
+    static constexpr int64_t kTileLatencyFrames = 1024;
     const bool seg_min_from_env_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES") != nullptr;
     int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))

@@ -366,6 +366,28 @@ def test_one_float32_pipe_buffer_per_call_takes_the_tile_form(sections):
         assert not ex.kernel_name().startswith("biquad_tile_kernel") and not b64.kernel_name().startswith("biquad_tile_kernel")
 
 
+@pytest.mark.parametrize("lines,channels", [(16, 8), (100, 2), (200, 1), (37, 3)])
+def test_long_buffers_of_many_series_take_the_tile_form(lines, channels):
+    """A multi-Line pipe's step -- every Line's one pipe buffer in one call (multiLineExecutor, run.go:112-132, through
+    pipe_hip_process_lines / process_batch): 65 - 255 series of 4096 frames are neither 2^20 samples nor "at most 64
+    series", and until round 6 fell between the two rules onto the ordered form (16 Lines x 8 ch: 117 us; the tile form:
+    11, profiles/r06_biquad_dispatch_gap.txt).  The rule is the buffer's LENGTH: 1024 frames or more a Line.  Under this
+    file's bound, two calls (the state carries); a call of 1000 frames a Line keeps the ordered form, bit for bit."""
+    q = coeffs(1)
+    F = 4096
+    x = np.stack([synth.samples(synth.line_seed(60 + l), 0, 2 * F * channels, np.float32).reshape(2 * F, channels) for l in range(lines)])
+    want = oracle(q, x)
+    got, name = run(q, x, lines, 2, exact=False)
+    assert name.startswith("biquad_tile_kernel"), name
+    w32 = want.astype(np.float32)
+    err = np.abs(got.astype(np.float64) - w32.astype(np.float64)) / relaxed_ulp(q, want)
+    assert err.max() <= 1.0, err.max()
+    assert (got != w32).sum() <= max(4, got.size // 100000)
+    short, sname = run(q, x[:, :1000], lines, 1, exact=False)
+    assert not sname.startswith("biquad_tile_kernel"), sname
+    assert np.array_equal(short, w32[:, :1000])
+
+
 @pytest.mark.parametrize("sections", [1, 2])
 def test_float64_buffers_take_the_tile_form_only_when_asked(sections):
     """PIPE_HIP_PARAM_RELAXED_F64: the buffers the Go pipe carries (pipe.go:394,437: float64) may take the tile form
