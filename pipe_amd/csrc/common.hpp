@@ -207,7 +207,7 @@ struct pipe_hip_processor {
     pipe_hip_config cfg{};
     // the shipped tuning knobs, read from the environment when the handle is made (init_common)
     struct Knobs {
-        int64_t fir_ols_min_items = -1;     // PIPE_HIP_FIR_OLS_MIN_ITEMS: smallest call (1024-point transforms) for the overlap-save FIR (default 4 per CU)
+        int64_t fir_ols_min_items = -1;     // PIPE_HIP_FIR_OLS_MIN_ITEMS: smallest call (1024-point transforms) for the overlap-save FIR (default: by taps and samples, fir.hip ols_wanted)
         int64_t fir_mfma_min_passes = 32;   // PIPE_HIP_FIR_MFMA_MIN_PASSES: smallest call (passes of 1024 frames x 2 ch) for the matrix-pipe FIR
         size_t overlap_min_bytes = (size_t)4 << 20;  // PIPE_HIP_OVERLAP_MIN_BYTES: smallest host call cut into overlapped chunks of Lines
         size_t zero_copy_max = (size_t)1 << 20;      // PIPE_HIP_ZERO_COPY_MAX: largest buffer the kernels read / write in pinned host memory

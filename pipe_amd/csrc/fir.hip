@@ -25,6 +25,7 @@
 //     workgroup barrier) and leave as fully coalesced stores.
 // The kernel is bound by the f64 VALU rate (2*N flop per scalar sample against
 // 8 B of HBM traffic): DESIGN.md "Kernels and their rooflines".
+#include <cmath>
 #include <cstdlib>
 
 #include <hip/hip_ext.h>
@@ -585,7 +586,7 @@ public:
         // direct form (bit-exact).
         // (a run that is queued behind a doorbell keeps to the direct form: nothing in it allocates or synchronises)
         if (ols_ && !exact_ && !queued_run && (out_dtype == PIPE_HIP_F32 || relaxed_f64_out || relaxed_f64_) &&
-            ols_->items(frames, cfg.channels, nl) >= ols_min_items() &&
+            ols_wanted(frames, nl) &&
             (!ols_->partitioned() || (reinterpret_cast<uintptr_t>(d_in) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(in_dtype)) == 0 &&
                                        reinterpret_cast<uintptr_t>(d_out) % ((cfg.channels == 1 ? 1 : 2) * dtype_size(out_dtype)) == 0))) {
             PH_TRY(ols_->run(d_in, in_dtype, d_out, out_dtype, hist, hist_next() + hoff, frames, cfg.channels,
@@ -669,14 +670,32 @@ public:
     }
 
 private:
-    // The overlap-save launch costs 15 - 17 us whatever it carries up to a unit a wave (2048 transforms on 256 CUs: a lone
-    // wave's unit is that long); the ordered form on the matrix pipe starts at 9 us and grows by 5 us per 512 transforms.
-    // They cross between 800 (one long Line) and 1000 transforms (many one-buffer Lines): 4 a CU.  (8 a CU until round
-    // 6 -- measured against the VALU direct form, before the matrix-pipe form existed: calls of 1024 - 2047 transforms
-    // took 19 - 34 us where overlap-save takes 16 - 17, profiles/r06_fir_small_calls.txt.)
-    int64_t ols_min_items() const
+    // Where a device-resident call crosses from the ordered form on the matrix pipe to overlap-save
+    // (profiles/r06_fir_small_calls.txt: scripts/fir_small_calls_probe.py over 32 ... 4096 taps, one long Line and many
+    // one-buffer Lines).  The ordered form is 4.5 us + 2.8 ps a sample + 0.060 ps a sample and tap at every tap count.
+    // An overlap-save launch has a floor, whatever it carries up to a unit a wave (2048 transforms on 256 CUs: a lone
+    // wave's unit is that long): 15 - 18 us with one spectrum; partitioned (P = ceil(taps / 512), every run starts with
+    // P - 1 transforms of warm-up) 13.8 P^1.5 us for one long Line ... 18.8 P^1.5 for 128 Lines and more (39 / 105 / 310
+    // and 53 / 150 / 420 us at 1024 / 2048 / 4096 taps).  Overlap-save where the ordered form's estimate passes that:
+    //     one spectrum:  frames x channel pairs x (taps + 45) >= 2.0e8     (256 taps: 860 transforms; 32: 2600; 512: 700)
+    //     partitioned:   4.5 + frames x channel pairs x (2.76e-6 + 6.0e-8 taps) >= the floor
+    // -- until round 6 the rule was "8 transforms a CU" whatever the taps and the shape, set against the VALU direct form
+    // before the matrix-pipe form existed: calls of 1024 - 2047 transforms of a 256-tap filter took 19 - 34 us where
+    // overlap-save takes 16 - 17, 256 one-buffer Lines of a 4096-tap filter 418 us where the ordered form takes 330.
+    // PIPE_HIP_FIR_OLS_MIN_ITEMS set: that count of transforms alone.
+    bool ols_wanted(int64_t frames, int nl) const
     {
-        return knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 4 * (int64_t)cus_;
+        const int64_t items = ols_->items(frames, cfg.channels, nl);
+        if (knobs.fir_ols_min_items >= 0)
+            return items >= knobs.fir_ols_min_items;
+        const double chip = (double)cus_ / 256.0;  // (the constants are a 256-CU chip's)
+        const double pair_frames = (double)frames * (double)nl * (double)((cfg.channels + 1) / 2);
+        if (!ols_->partitioned())
+            return pair_frames * (double)(N_ + 45) >= 2.0e8 * chip;
+        const double P = (double)ols_->partitions();
+        const double spread = nl <= 1 ? 0.0 : (nl >= 128 ? 1.0 : (double)(nl - 1) / 127.0);
+        const double floor_us = (13.8 + 5.0 * spread) * P * std::sqrt(P);
+        return 4.5 + pair_frames * (2.76e-6 + 6.0e-8 * (double)N_) / chip >= floor_us;
     }
 
     // the history of all Lines into the other half of the double buffer in the other element type

@@ -541,6 +541,7 @@ int Plan::set_taps(const double *taps, hipStream_t s)
 }
 
 bool Plan::partitioned() const { return impl_->P > 1; }
+int Plan::partitions() const { return impl_->P; }
 
 int64_t Plan::items(int64_t frames, int channels, int lines) const
 {

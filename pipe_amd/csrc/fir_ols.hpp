@@ -31,6 +31,7 @@ public:
 
     // filters above 512 taps run partitioned, on the 32 x 32 kernel only: 16-byte aligned buffers
     bool partitioned() const;
+    int partitions() const;  // 1, or ceil(taps / 512)
 
     const Impl &impl() const { return *impl_; }
 

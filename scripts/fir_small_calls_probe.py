@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pipe_amd import processors as P, synth  # noqa: E402
 
-F, C, N = 4096, int(os.environ.get("PROBE_C", "2")), 256
+F, C, N = 4096, int(os.environ.get("PROBE_C", "2")), int(os.environ.get("PROBE_TAPS", "256"))
 taps = synth.fir_lowpass_taps(N, f32_rounded=True)
 st = torch.cuda.Stream()
 SHAPES = [(1, 8), (1, 16), (1, 32), (1, 64), (1, 96), (1, 128), (1, 192), (1, 256), (1, 384), (1, 512), (1, 1024),
@@ -21,7 +21,7 @@ if os.environ.get("PROBE_SHAPES"):   # "lines,buffers;..."
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["PROBE_SHAPES"].split(";")]
 for lines, K in SHAPES:
     n = lines * K * F * C
-    items = lines * -(-K * F // 769) * -(-C // 2)
+    items = lines * -(-K * F // (1025 - N if N <= 512 else 512)) * -(-C // 2)
     d_in = torch.empty(n, dtype=torch.float32, device="cuda")
     P.synth_fill(d_in, synth.line_seed(0))
     d_out = torch.empty_like(d_in)

@@ -74,7 +74,7 @@ def test_default_line_has_every_contract_field():
     assert bs["kernel"].startswith("biquad_tile_kernel") and bs["algorithmic_bytes_per_launch"] == 16 * 8 * 512 * 4096 * 8
     assert 0.3 < bs["roofline_frac"] < 0.85
     # SURVEY 8(d)'s "C2" resident shape to the letter: 1 Line x 256 buffers, one launch (1364 transforms: overlap-save
-    # since the 4-a-CU rule of round 6; a launch of this size is as long as a lone wave's unit)
+    # since round 6's dispatch rule; a launch of this size is as long as a lone wave's unit)
     c2 = d["c2_k256"]
     assert c2["kernel"].startswith("fir_ols_kernel") and c2["algorithmic_bytes_per_launch"] == 8 * 256 * 4096 * 2
     assert c2["sets"] >= 2 and c2["sets"] * c2["set_bytes"] >= 512 << 20 and 0 < c2["roofline_frac"] < 0.44

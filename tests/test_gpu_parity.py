@@ -176,7 +176,8 @@ def test_fir_full_size_properties(pinned):
     #  (b) a spot-checked window equals the oracle run on just that window + history;
     #  (c) a delayed unit impulse reproduces the taps at the far end of the stream.
     # pinned: PIPE_HIP_PARAM_EXACT -- the ordered forms, bit for bit.  Not pinned: the library's own dispatch, which from
-    # round 6 takes the overlap-save form for the whole stream (1364 transforms >= 4 a CU) and the ordered form for its
+    # round 6 takes the overlap-save form for the whole stream (1364 transforms: past the 860 where the forms cross at 256
+    # taps, fir.hip ols_wanted) and the ordered form for its
     # two parts (533 and 831): the same properties within the overlap-save contract (tests/_tol.py fir_ulps <= 1).
     from tests import _tol
     F, C, N, K = 4096, 2, 256, 256
