@@ -1550,7 +1550,9 @@ public:
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
         // 3 or 4 sections: the tile kernel holds two, so two tile passes over the halves of the cascade with a float64
         // stream between them (24 bytes a sample instead of 8) -- where the lane walk crawls (few Lines or channels)
-        if (relaxed && S_ > kTileMaxSections && S_ <= 2 * kTileMaxSections && tc <= 8 && frames * a.nseries >= seg_min_samples_ &&
+        // (a LONG buffer of few series here too, since round 6: one 4096 x 2 float32 buffer through four sections took the
+        // ordered form's 100 us where the two tile passes take 24, profiles/r06_biquad_dispatch_gap.txt)
+        if (relaxed && S_ > kTileMaxSections && S_ <= 2 * kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
             frames >= tile_min_frames_ && split_wanted(nl))
             return run_split(d_in, in_dtype, d_out, out_dtype, frames, a, s);
         if (ext_state_ && !tiled)

@@ -47,7 +47,7 @@ def kappa(q):
 def biquad_ulp(q, want):
     """time-segmented biquad: one float32 ulp measured at max(|y|, 2^-19 kappa max|y of the Line|); want: [lines][frames][C]."""
     floor = (2.0 ** -19 * kappa(q) * np.abs(want).max(axis=(1, 2), keepdims=True)).astype(np.float32)
-    return np.spacing(np.maximum(np.abs(want), floor)).astype(np.float64)
+    return np.spacing(np.maximum(np.abs(want).astype(np.float32), floor)).astype(np.float64)   # (a float32 ulp whatever `want`'s type)
 
 
 def chain_ulps(got, want64):

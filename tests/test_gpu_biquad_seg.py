@@ -62,7 +62,8 @@ def kappa(q):
 def relaxed_ulp(q, want):
     """include/pipe_hip.h: one float32 ulp measured at max(|y|, 2^-19 * kappa * the Line's full scale)."""
     floor = (2.0 ** -19 * kappa(q) * np.abs(want).max(axis=(1, 2), keepdims=True)).astype(np.float32)
-    return np.spacing(np.maximum(np.abs(want), floor)).astype(np.float64)
+    # (a FLOAT32 ulp whatever type `want` came in: the spacing of a float64 magnitude is 2^29 times finer)
+    return np.spacing(np.maximum(np.abs(want).astype(np.float32), floor)).astype(np.float64)
 
 
 def run(q, x, lines, calls, exact, dtype_out=np.float32, monkeypatch=None):
@@ -366,14 +367,16 @@ def test_one_float32_pipe_buffer_per_call_takes_the_tile_form(sections):
         assert not ex.kernel_name().startswith("biquad_tile_kernel") and not b64.kernel_name().startswith("biquad_tile_kernel")
 
 
-@pytest.mark.parametrize("lines,channels", [(16, 8), (100, 2), (200, 1), (37, 3)])
-def test_long_buffers_of_many_series_take_the_tile_form(lines, channels):
+@pytest.mark.parametrize("lines,channels,sections", [(16, 8, 1), (100, 2, 1), (200, 1, 1), (37, 3, 1), (1, 2, 4), (16, 8, 3), (100, 2, 4)])
+def test_long_buffers_of_many_series_take_the_tile_form(lines, channels, sections):
     """A multi-Line pipe's step -- every Line's one pipe buffer in one call (multiLineExecutor, run.go:112-132, through
     pipe_hip_process_lines / process_batch): 65 - 255 series of 4096 frames are neither 2^20 samples nor "at most 64
     series", and until round 6 fell between the two rules onto the ordered form (16 Lines x 8 ch: 117 us; the tile form:
     11, profiles/r06_biquad_dispatch_gap.txt).  The rule is the buffer's LENGTH: 1024 frames or more a Line.  Under this
-    file's bound, two calls (the state carries); a call of 1000 frames a Line keeps the ordered form, bit for bit."""
-    q = coeffs(1)
+    file's bound, two calls (the state carries); a call of 1000 frames a Line keeps the ordered form, bit for bit.
+    Three and four sections (two tile passes over the halves of the cascade) come under the same rule: one 4096 x 2
+    buffer through four sections 100 -> 24 us."""
+    q = coeffs(sections)
     F = 4096
     x = np.stack([synth.samples(synth.line_seed(60 + l), 0, 2 * F * channels, np.float32).reshape(2 * F, channels) for l in range(lines)])
     want = oracle(q, x)
@@ -382,7 +385,8 @@ def test_long_buffers_of_many_series_take_the_tile_form(lines, channels):
     w32 = want.astype(np.float32)
     err = np.abs(got.astype(np.float64) - w32.astype(np.float64)) / relaxed_ulp(q, want)
     assert err.max() <= 1.0, err.max()
-    assert (got != w32).sum() <= max(4, got.size // 100000)
+    # ("almost every sample": two tile passes round twice -- measured 1.3 per 100 000 with three sections of kappa 21)
+    assert (got != w32).sum() <= max(4, got.size // (100000 if sections <= 2 else 50000))
     short, sname = run(q, x[:, :1000], lines, 1, exact=False)
     assert not sname.startswith("biquad_tile_kernel"), sname
     assert np.array_equal(short, w32[:, :1000])

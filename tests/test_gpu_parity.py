@@ -272,6 +272,10 @@ def test_biquad_cascade_per_buffer_bit_exact(dtype, channels, sections, F):
     x = sig(7, sum(lens), channels, dtype)
     ref = O.Biquad(q, channels)
     with P.Biquad(q, F, channels, dtype=dtype) as p:
+        # (pinned: since round 6 a float32 buffer of 1024 frames or more through three or four sections takes the two tile
+        # passes like one through one or two sections since round 4 -- tests/test_gpu_biquad_seg.py; this test is the
+        # ordered cascade's)
+        p.set_exact(True)
         p.start()
         pos = 0
         for n in lens:
@@ -279,6 +283,7 @@ def test_biquad_cascade_per_buffer_bit_exact(dtype, channels, sections, F):
             want = expect(ref.process(x[pos:pos + n].astype(np.float64)).reshape(n, channels), dtype)
             assert np.array_equal(got, want), (pos, n)
             pos += n
+        assert "tile" not in p.kernel_name(), p.kernel_name()
         p.start()  # restart from silence
         ref = O.Biquad(q, channels)
         got = p.process(x[:F])
