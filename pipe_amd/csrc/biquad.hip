@@ -1517,8 +1517,11 @@ public:
         last_tile_.valid = false;
         last_oop_ = false;
         // (small calls are launch-bound either way and stay bit-exact, like the FIR's)
+        // (... or LONG: see long_few below -- more than 8 channels cannot take the tile form, and one 4096 x 16 float32
+        // buffer a call took the ordered form's 141 us where the lane walk over segments takes 14)
         bool segmented = relaxed && S_ <= kMaxSegSections && frames >= 4 * kChunk && a.nseries < 65536 &&
-                         frames * a.nseries >= seg_min_samples_;
+                         (frames * a.nseries >= seg_min_samples_ ||
+                          (cfg.channels > 8 && !seg_min_from_env_ && frames >= kTileLatencyFrames));
         if (segmented) {
             // few series: lanes are (segment, series) pairs, more and shorter segments (the serial scan over them
             // bounds their number)
