@@ -81,13 +81,16 @@ def test_rows_form_streams_bit_exact(monkeypatch, dtype, up, down, T, C):
 
 
 def test_rows_form_is_the_default_for_long_streams_of_four_channels_and_more():
-    """Default threshold: one 4096-frame pipe buffer stays on the tiled kernel, a long resident 8-channel stream takes
-    the rows; a stereo stream of the same length keeps the wave kernel (level with the rows: not switched)."""
+    """Default thresholds: 8 channels take the rows from the first block (one 4096-frame pipe buffer a call: 11.7 us
+    against the tiled kernel's 16.7 -- since round 6, profiles/r06_dispatch_audit.txt); 4 channels keep one pipe buffer
+    on the tiled kernel (11.8 against 13.0 us) and take the rows from 64 blocks; a stereo stream keeps the wave kernel
+    (level with the rows: not switched)."""
     up, down, T, F = 160, 147, 24, 4096
     proto = synth.resampler_proto(up, down, T)
-    K = 40   # 64 blocks of 16 rows need 64 x 16 x 147 = 150 528 frames
-    n = K * F
-    for C, short_kernel, long_kernel in ((8, "resample_tiled_kernel", "resample_rows_kernel"), (2, "resample_wave_kernel", "resample_wave_kernel")):
+    # (64 blocks of 16 rows of 8 channels need 64 x 16 x 147 = 150 528 frames; of 32 rows of 4 channels twice that)
+    for C, K, short_kernel, long_kernel in ((8, 40, "resample_rows_kernel", "resample_rows_kernel"), (4, 80, "resample_tiled_kernel", "resample_rows_kernel"),
+                                            (2, 40, "resample_wave_kernel", "resample_wave_kernel")):
+        n = K * F
         x = synth.samples(synth.line_seed(51), 0, n * C).reshape(n, C).astype(np.float32)
         cap = -(-n * up // down) + 1
         ref = O.Resampler(proto, T, up, down, C)
