@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Audit of the library's size-dependent dispatch rules: for every shape of a sweep, the library's own choice against
 each alternative form that an environment knob can force, host time a call (200 calls back to back on one stream).
-A shape whose default is more than 25 % slower than an alternative is flagged -- round 6 found four rules that were
+A shape whose default is more than 25 % slower than an alternative is flagged -- round 6 found five rules that were
 right only at the one shape their round had measured (profiles/r06_fir_small_calls.txt, r06_biquad_dispatch_gap.txt).
     python scripts/dispatch_audit.py            (one MI355X, ~1 minute)
 Exit status 1 when a shape is flagged."""
@@ -101,6 +101,20 @@ for lines, C, K in ((8, 8, 1), (16, 8, 1), (32, 8, 1), (64, 8, 1), (64, 2, 1), (
           lambda: P.Chain([P.Fir(taps, F, C, **kw), P.Biquad(q1, F, C, **kw), P.Gain(0.7071067811865476, F, C, **kw)]),
           lambda p: p.process_batch(d_in, d_out, K * F, stream=st.cuda_stream),
           [("fused", {"PIPE_HIP_FIR_OLS_MIN_ITEMS": "1"}), ("staged", {"PIPE_HIP_FIR_OLS_MIN_ITEMS": "1000000000"})])
+
+# ---- resampler: the row form against the tiled kernel (4 channels and more, float32)
+T, up, down = 24, 160, 147
+proto = synth.resampler_proto(up, down, T)
+for lines, C, K in ((1, 8, 1), (1, 8, 16), (16, 8, 1), (1, 16, 4), (1, 4, 16), (16, 4, 1), (1, 6, 16), (1, 8, 64), (64, 4, 4)):
+    n_in = K * F
+    cap = -(-n_in * up // down) + 1
+    d_in = torch.empty(lines * n_in * C, dtype=torch.float32, device="cuda")
+    P.synth_fill(d_in, synth.line_seed(0))
+    d_out = torch.empty(lines * cap * C, dtype=torch.float32, device="cuda")
+    audit(f"resampler 160/147, {lines:3d} Lines x {C:2d} ch x {K:4d} buffers",
+          lambda: P.Resampler(proto, T, up, down, F, C, dtype=np.float32, lines=lines, max_batch=K),
+          lambda p: p.resample_batch(d_in, n_in, d_out, cap, stream=st.cuda_stream),
+          [("rows", {"PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS": "1"}), ("tiled", {"PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS": "1000000000"})])
 
 print(f"{len(flagged)} shape(s) flagged" + (": " + "; ".join(flagged) if flagged else ""))
 sys.exit(1 if flagged else 0)

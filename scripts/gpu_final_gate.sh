@@ -27,6 +27,12 @@ for sc in stress_fused:12 stress_biquad_seg:6 stress_fir_mfma:6 stress_long_fir:
   echo "soak $name $arg: rc $rc in $(( $(date +%s) - ts )) s: $(tail -1 $OUT/$name.txt | cut -c1-160)" >> $R
   [ $rc -ne 0 ] && rc_k=1
 done
+# the size-dependent dispatch rules against every form a knob can force (round 6: five rules were right only at the
+# shape their round had measured); exit 1 = a default more than 25 % behind an alternative
+ts=$(date +%s)
+timeout 400 python scripts/dispatch_audit.py > $OUT/dispatch_audit.txt 2>&1; rc_a=$?
+echo "dispatch audit: rc $rc_a in $(( $(date +%s) - ts )) s: $(tail -1 $OUT/dispatch_audit.txt | cut -c1-200)" >> $R
+[ $rc_a -ne 0 ] && rc_k=1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; rc_s=$?
 echo "smoke(): rc $rc_s: $(grep -E '^smoke' $OUT/smoke.txt | tail -1)" >> $R
 timeout 600 python bench.py --gpus 1 > $OUT/bench.txt 2> $OUT/bench.err; rc_b=$?
