@@ -211,7 +211,7 @@ struct pipe_hip_processor {
         int64_t fir_mfma_min_passes = 32;   // PIPE_HIP_FIR_MFMA_MIN_PASSES: smallest call (passes of 1024 frames x 2 ch) for the matrix-pipe FIR
         size_t overlap_min_bytes = (size_t)4 << 20;  // PIPE_HIP_OVERLAP_MIN_BYTES: smallest host call cut into overlapped chunks of Lines
         size_t zero_copy_max = (size_t)1 << 20;      // PIPE_HIP_ZERO_COPY_MAX: largest buffer the kernels read / write in pinned host memory
-        int64_t resample_rows_min_blocks = 64;  // PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS: smallest call (blocks of 128 / C rows of a period each) for the row form of the resampler (unset: 8 channels and more from the first block, resampler.hip); negative: never
+        int64_t resample_rows_min_blocks = 64;  // PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS: smallest call (blocks of 128 / C rows of a period each) for the row form of the resampler (unset: 6 channels and more from the first block, resampler.hip); negative: never
         bool resample_rows_stereo = false;      //   ... set explicitly, it also admits 2-channel streams (they tie with the wave kernel: profiles/r05_resampler_rows_sweep.txt)
         int bar_upload = -1;                // PIPE_HIP_BAR_UPLOAD: 0 never, 1 also without an HDP flush register, unset: where the device has one
         void read();

@@ -1403,10 +1403,11 @@ private:
         const int64_t rows_per_line = last_row - first_row + 1;
         const int64_t blocks_per_line = (rows_per_line + rpb - 1) / rpb;
         // whole workgroups of rows, and enough of them: the wave kernel keeps the short calls
-        // (8 channels and more: from the first block -- one Line x 8 ch x 4 .. 32 buffers 13.3 - 13.7 us against the
-        // tiled kernel's 17.7 - 18.6, profiles/r06_dispatch_audit.txt; 4 channels: the tiled kernel keeps the short calls,
-        // 11.8 against 13.0; PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS set: that count for every channel count)
-        const int64_t min_blocks = !knobs.resample_rows_stereo && C >= 8 ? 1 : knobs.resample_rows_min_blocks;
+        // (6 channels and more: from the first block -- one Line x 8 ch x 4 .. 32 buffers 13.3 - 13.7 us against the
+        // tiled kernel's 17.7 - 18.6, 6 ch x 16 buffers 13.1 against 16.7, profiles/r06_dispatch_audit.txt; 4 channels: the
+        // tiled kernel keeps the short calls, 11.8 against 13.0; PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS set: that count for
+        // every channel count)
+        const int64_t min_blocks = !knobs.resample_rows_stereo && C >= 6 ? 1 : knobs.resample_rows_min_blocks;
         if (rows_per_line * 4 < blocks_per_line * rpb * 3 || (int64_t)cfg.lines * blocks_per_line < min_blocks)
             return false;
         // 32-bit sample arithmetic in the kernel

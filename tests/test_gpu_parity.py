@@ -406,7 +406,7 @@ def test_resampler_large_tap_table_stays_on_the_tiled_kernel(dtype, channels, T,
 def test_resampler_wide_float32_lines_take_the_pair_window_and_stay_bit_exact(channels, T, up, down, monkeypatch):
     """float32 streams of four or more channels keep the staged window as float32 channel pairs (one LDS
     read per frame and pair, widened in registers): exact, so still the oracle's bits -- per buffer with a
-    carried history, and as one device-resident batch of several Lines.  (The tiled kernel's test: 8 channels take
+    carried history, and as one device-resident batch of several Lines.  (The tiled kernel's test: 6 channels and more take
     the row form from the first block since round 6 -- tests/test_gpu_resampler_rows.py -- so it is kept out here.)"""
     monkeypatch.setenv("PIPE_HIP_RESAMPLE_ROWS_MIN_BLOCKS", "1000000000")
     F, lines = 2048, 3

@@ -81,7 +81,7 @@ def test_rows_form_streams_bit_exact(monkeypatch, dtype, up, down, T, C):
 
 
 def test_rows_form_is_the_default_for_long_streams_of_four_channels_and_more():
-    """Default thresholds: 8 channels take the rows from the first block (one 4096-frame pipe buffer a call: 11.7 us
+    """Default thresholds: 6 channels and more take the rows from the first block (one 4096-frame pipe buffer a call: 11.7 us
     against the tiled kernel's 16.7 -- since round 6, profiles/r06_dispatch_audit.txt); 4 channels keep one pipe buffer
     on the tiled kernel (11.8 against 13.0 us) and take the rows from 64 blocks; a stereo stream keeps the wave kernel
     (level with the rows: not switched)."""
