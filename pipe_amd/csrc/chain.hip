@@ -67,7 +67,26 @@ public:
                 const int64_t items = ((frames + L - 1) / L) * ((cfg.channels + 1) / 2) * (int64_t)cfg.lines;
                 if (!fused_)
                     fused_.reset(new fused::Plan());
-                if (items >= fv.min_items && fused_->accepts(bv.coeffs, bv.sections, fv.ntaps, frames, s)) {
+                // Where the one kernel passes the three launches (profiles/r06_chain_small_calls.txt: 64 / 256 / 512 taps,
+                // 2 and 8 channels).  Its launch has a floor: 18 - 19 us when every workgroup owns whole Lines (the
+                // block-local look-back: Lines a multiple of the CUs, or eight times as many), 29 - 31 us with the global
+                // look-back; the staged chain is 17.5 us + the ordered FIR's 2.76 ps a sample and 0.060 ps a sample and tap
+                // + the biquad's and the gain's 7 ps a sample.  Whole Lines per workgroup: from two transforms a CU, as
+                // before; otherwise where the two lines cross,
+                //     frames x Lines x channel pairs x (taps + 116) >= 1.92e8     (256 taps: 32 Lines x 8 ch x 4096)
+                // -- until round 6 two transforms a CU for every shape and tap count: 128 Lines x 2 ch through 64 taps
+                // took the fused kernel's 30.7 us where the three launches take 20.8.  PIPE_HIP_FIR_OLS_MIN_ITEMS set:
+                // that count of transforms alone.
+                bool wanted;
+                if (fv.min_items >= 0) {
+                    wanted = items >= fv.min_items;
+                } else {
+                    const int cus = fv.cus > 0 ? fv.cus : 256;
+                    const bool whole_lines = cfg.lines >= cus && (cfg.lines % cus == 0 || cfg.lines >= 8 * cus);
+                    const double pf = (double)frames * (double)cfg.lines * (double)((cfg.channels + 1) / 2);
+                    wanted = whole_lines ? items >= 2 * (int64_t)cus : pf * (double)(fv.ntaps + 116) >= 1.92e8 * (double)cus / 256.0;
+                }
+                if (wanted && fused_->accepts(bv.coeffs, bv.sections, fv.ntaps, frames, s)) {
                     if (!stages[0]->fuse_view_fir(&fv, s, true))  // (history into the fused kernel's layout)
                         return PIPE_HIP_EHIP;
                     PH_TRY(fused_->run(fv, bv, has_gain, g, d_in, d_out, f64, frames, cfg.channels, cfg.lines, s, &timer,

@@ -348,7 +348,8 @@ struct pipe_hip_processor {
         const double *taps;    // float64 taps on the device (the direct form's copy)
         int ntaps;
         bool relaxed;          // the stage may use a form that is not bit-exact
-        int64_t min_items;     // smallest call (in FFT items) that takes the overlap-save form
+        int64_t min_items;     // smallest call (in FFT items) that takes the fused kernel: PIPE_HIP_FIR_OLS_MIN_ITEMS, or -1 = the chain's own rule (chain.hip)
+        int cus;               // compute units of the stage's device (that rule's constants are a 256-CU chip's)
         bool f64_stream;       // IN: the chain's buffers are float64 (the history then stays float64)
         bool relaxed_f64;      // PIPE_HIP_PARAM_RELAXED_F64 is set on the stage: float64 RESULTS may be relaxed too
     };

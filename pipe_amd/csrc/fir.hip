@@ -657,10 +657,9 @@ public:
         v->ntaps = N_;
         v->relaxed = !exact_;
         v->relaxed_f64 = relaxed_f64_;
-        // (the fused chain replaces THREE launches and 4x the traffic: it pays from two transforms per CU, where the
-        // FIR alone needs eight to beat its direct form -- 64 Lines x 8 ch x 4096, a rank's share of configs[3] at
-        // 8 GPUs: 0.048 ms staged)
-        v->min_items = knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : 2 * (int64_t)cus_;
+        // (the fused chain replaces THREE launches and 4x the traffic: where it pays is the chain's rule, chain.hip)
+        v->min_items = knobs.fir_ols_min_items >= 0 ? knobs.fir_ols_min_items : -1;
+        v->cus = cus_;
         return true;
     }
     int fuse_commit_fir(hipStream_t s) override

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pipe_amd import processors as P, synth  # noqa: E402
 
-F, N = 4096, 256
+F, N = 4096, int(os.environ.get("PROBE_TAPS", "256"))
 taps = synth.fir_lowpass_taps(N, f32_rounded=True)
 q = synth.biquad_rbj_lowpass()
 st = torch.cuda.Stream()
