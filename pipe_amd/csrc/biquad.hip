@@ -1329,7 +1329,7 @@ public:
         const int64_t nseries = (int64_t)cfg.lines * cfg.channels;
         const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames;
         return S_ <= kTileMaxSections && cfg.channels <= 8 && (frames * nseries >= seg_min_samples_ || long_few) &&
-               frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") && !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS") &&
+               frames >= tile_min_frames() && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") && !PH_ENV_AB("PIPE_HIP_BIQUAD_TWO_PASS") &&
                !(cfg.channels >= kTileWalkChannels && cfg.lines >= tile_walk_lines_);
     }
     void rollback_launch() override
@@ -1549,14 +1549,14 @@ public:
         const bool long_few = !seg_min_from_env_ && frames >= kTileLatencyFrames;
         a.state_out = a.state;
         const bool tiled = relaxed && S_ <= kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
-                           frames >= tile_min_frames_ && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") &&
+                           frames >= tile_min_frames() && !PH_ENV_AB("PIPE_HIP_BIQUAD_NO_TILE") &&
                            !(cfg.channels >= kTileWalkChannels && nl >= tile_walk_lines_ && segmented);
         // 3 or 4 sections: the tile kernel holds two, so two tile passes over the halves of the cascade with a float64
         // stream between them (24 bytes a sample instead of 8) -- where the lane walk crawls (few Lines or channels)
         // (a LONG buffer of few series here too, since round 6: one 4096 x 2 float32 buffer through four sections took the
         // ordered form's 100 us where the two tile passes take 24, profiles/r06_biquad_dispatch_gap.txt)
         if (relaxed && S_ > kTileMaxSections && S_ <= 2 * kTileMaxSections && tc <= 8 && (frames * a.nseries >= seg_min_samples_ || long_few) &&
-            frames >= tile_min_frames_ && split_wanted(nl))
+            frames >= tile_min_frames() && split_wanted(nl))
             return run_split(d_in, in_dtype, d_out, out_dtype, frames, a, s);
         if (ext_state_ && !tiled)
             return PIPE_HIP_EINVAL;  // (only the one-pass tile kernel knows the stride: run_split checked)
@@ -2233,9 +2233,20 @@ private:
     int64_t seg_min_samples_ = std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES")
                                          ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES"))
                                          : (int64_t)1 << 20;
-    const int64_t tile_min_frames_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
-                                         ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES"))
-                                         : 512;  // (shorter Lines leave the tiles mostly empty: 16384 x 1 ch x 128 frames 38 Gsamples/s against the lane walk's 87; at 256 frames even, at 512 150 against 88)
+    // Shortest Line (frames a call) for the LDS-tile form; shorter Lines leave the tiles mostly empty and keep the lane walk.
+    // By channels since round 6 (scripts/dev/tile_min_frames_probe.py, profiles/r06_dispatch_audit.txt: 128 .. 512 frames x
+    // 1 .. 8 channels over 2^21 and 2^23 samples): 8 channels from 256 frames (8.5 against 11.4 us), 2 and 4 channels from 320
+    // (2 ch x 384 frames x 2730 Lines: 14.4 against 24.3 us), the others from 384 -- it was 512 for all (mono Lines of 256
+    // frames: the tile form 30.0 us, the lane walk 22.8).  PIPE_HIP_BIQUAD_TILE_MIN_FRAMES set: that count for all.
+    const int64_t tile_min_frames_env_ = std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES")
+                                             ? std::atoll(std::getenv("PIPE_HIP_BIQUAD_TILE_MIN_FRAMES"))
+                                             : -1;
+    int64_t tile_min_frames() const
+    {
+        if (tile_min_frames_env_ >= 0)
+            return tile_min_frames_env_;
+        return cfg.channels == 8 ? 256 : (cfg.channels == 2 || cfg.channels == 4 ? 320 : 384);
+    }
     static int walk_lines_knob()
     {
         const char *e = PH_ENV_AB("PIPE_HIP_BIQUAD_TILE_WALK_LINES");

@@ -257,10 +257,11 @@ def test_three_and_four_sections_run_as_two_tile_passes(sections, lines, channel
 
 
 def test_calls_shorter_than_512_frames_keep_the_lane_walk(monkeypatch):
-    """The shipped threshold: Lines of fewer than 512 frames a call would leave the tiles mostly empty."""
+    """The shipped threshold for stereo Lines: fewer than 320 frames a call would leave the tiles mostly empty (512 until
+    round 6; by channels now: test_short_lines_take_the_tile_form_by_channels)."""
     monkeypatch.setenv("PIPE_HIP_BIQUAD_SEG_MIN_SAMPLES", "1")
     q = coeffs(1)
-    for frames, form in ((511, "biquad_kernel"), (512, "biquad_tile_kernel")):
+    for frames, form in ((319, "biquad_kernel"), (320, "biquad_tile_kernel"), (512, "biquad_tile_kernel")):
         x = np.stack([synth.samples(synth.line_seed(500 + l), 0, frames * 2, np.float32).reshape(frames, 2) for l in range(64)])
         got, name = run(q, x, 64, 1, exact=False)
         assert form in name and "segmented" in name, name
@@ -392,6 +393,24 @@ def test_long_buffers_of_many_series_take_the_tile_form(lines, channels, section
     short, sname = run(q, x[:, :1000], lines, 1, exact=False)
     assert not sname.startswith("biquad_tile_kernel") and "segmented" not in sname, sname
     assert np.array_equal(short, w32[:, :1000])
+
+
+@pytest.mark.parametrize("lines,channels,frames,tile", [(2800, 2, 384, True), (3300, 2, 320, True), (4200, 2, 256, False), (1100, 8, 256, True),
+                                                        (1400, 8, 128, False), (5600, 1, 384, True), (6600, 1, 320, False), (1400, 4, 320, True),
+                                                        (1900, 3, 384, True), (2200, 3, 320, False)])
+def test_short_lines_take_the_tile_form_by_channels(lines, channels, frames, tile):
+    """Thousands of short Lines in one call (>= 2^20 samples): the shortest Line the LDS-tile form takes depends on the
+    channel count since round 6 (8 channels 256 frames, 2 and 4 channels 320, the others 384; it was 512 for all --
+    profiles/r06_dispatch_audit.txt); below it the lane walk over segments.  Both under this file's bound."""
+    q = coeffs(1)
+    x = np.stack([synth.samples(synth.line_seed(200 + l), 0, frames * channels, np.float32).reshape(frames, channels) for l in range(lines)])
+    want = oracle(q, x)
+    got, name = run(q, x, lines, 1, exact=False)
+    assert name.startswith("biquad_tile_kernel") == tile and "segmented" in name, name
+    w32 = want.astype(np.float32)
+    err = np.abs(got.astype(np.float64) - w32.astype(np.float64)) / relaxed_ulp(q, want)
+    assert err.max() <= 1.0, err.max()
+    assert (got != w32).sum() <= max(4, got.size // 100000)
 
 
 @pytest.mark.parametrize("sections", [1, 2])
